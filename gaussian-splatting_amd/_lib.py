@@ -1,0 +1,58 @@
+"""ctypes binding of libgsplat_hip.so -- the C-ABI declared in include/gsplat.h.
+
+The library is the product: if it is missing or fails to load this module raises
+(there is no CPU or PyTorch fallback on this path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgsplat_hip.so")
+
+_vp, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gsplat.h one to one
+PROTOTYPES = {
+    "gs_version": (_i, []),
+    "gs_last_error": (C.c_char_p, []),
+    "gs_tile_size": (_i, []),
+    "gs_grad_row_floats": (_i, []),
+    "gs_preprocess_fwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 13 + [_vp]),
+    "gs_preprocess_bwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 19 + [_vp]),
+    "gs_scan_workspace_bytes": (_sz, [_ll]),
+    "gs_scan_tiles": (_i, [_ll, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gs_duplicate_with_keys": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gs_sort_workspace_bytes": (_sz, [_ll]),
+    "gs_sort_pairs": (_i, [_ll, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "gs_identify_tile_ranges": (_i, [_ll, _i, _vp, _vp, _vp]),
+    "gs_render_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "gs_render_bwd": (_i, [_i, _i] + [_vp] * 10 + [_f, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C gaussian-splatting_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "This back-end has no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,74 @@
+// Binning stage: duplicate every drawn Gaussian once per 16x16 tile its box overlaps, with a
+// 64-bit key = tile_id << 32 | depth_key (ascending key order == tile-major, far-to-near), and
+// find each tile's [start,end) in the sorted list.
+//
+// The reference has no binning (it splats each Gaussian over its box in one global far-to-near
+// order, gaussian_renderer/__init__.py:151-159, :366); the keys reproduce that order inside every
+// tile: descending depth, ties by ascending Gaussian index (the sort is stable and pairs are
+// emitted in index order).  Bit-exact against oracle/gs_oracle.c::gso_duplicate_with_keys.
+//
+// HBM-bound: 48 B record + 8 B (offset, count) read per drawn Gaussian, 12 B written per pair.
+#include "gsplat_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int tiles_x,
+                                                                   const float4* __restrict__ splat,
+                                                                   const uint32_t* __restrict__ offsets,
+                                                                   const uint32_t* __restrict__ tiles_touched,
+                                                                   uint64_t* __restrict__ keys,
+                                                                   uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (tiles_touched[i] == 0) return;
+    const float4 q1 = splat[3 * (size_t)i + 1];
+    const float4 q2 = splat[3 * (size_t)i + 2];
+    const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+    const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
+    const int tx0 = xmin / GS_TILE, tx1 = (xmax - 1) / GS_TILE + 1;
+    const int ty0 = ymin / GS_TILE, ty1 = (ymax - 1) / GS_TILE + 1;
+    const uint32_t dk = gs_depth_key_desc(q1.z);
+    size_t o = offsets[i];
+    for (int ty = ty0; ty < ty1; ++ty)
+        for (int tx = tx0; tx < tx1; ++tx) {
+            keys[o] = ((uint64_t)(uint32_t)(ty * tiles_x + tx) << 32) | dk;
+            vals[o] = (uint32_t)i;
+            ++o;
+        }
+}
+
+__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, const uint64_t* __restrict__ keys,
+                                                                    uint32_t* __restrict__ ranges) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * (size_t)t] = (uint32_t)i;
+    if (i == D - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * (size_t)t + 1] = (uint32_t)(i + 1);
+}
+
+}  // namespace
+
+extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* offsets,
+                                      const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
+                                      void* stream_) {
+    GS_REQUIRE(N >= 0 && W > 0, "bad arguments");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(splat && offsets && tiles_touched && keys && vals, "null buffer");
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream_, N,
+                       tiles_x, (const float4*)splat, offsets, tiles_touched, keys, vals);
+    GS_CHECK_LAUNCH("duplicate_with_keys");
+    return GS_OK;
+}
+
+extern "C" int gs_identify_tile_ranges(long long D, int num_tiles, const uint64_t* keys, uint32_t* ranges,
+                                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GS_REQUIRE(D >= 0 && num_tiles > 0 && ranges, "bad arguments");
+    GS_CHECK_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
+    if (D == 0) return GS_OK;
+    GS_REQUIRE(keys, "null keys");
+    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3(gs_div_up(D, 256)), dim3(256), 0, stream, D, keys, ranges);
+    GS_CHECK_LAUNCH("identify_tile_ranges");
+    return GS_OK;
+}

@@ -1,0 +1,74 @@
+// Shared definitions for the MI355X (gfx950) Gaussian rasterizer kernels.
+//
+// Data layout in HBM
+// ------------------
+// Inputs arrive exactly as the reference's rasterizer takes them
+// (reference gaussian_renderer/__init__.py:76-86): means3D (N,3), scales (N,3),
+// rotations (N,4), opacities (N,1), shs (N,K,3), colors_precomp (N,3),
+// cov3D_precomp (N,6); all fp32, contiguous.
+//
+// The preprocess kernel packs everything the per-tile kernels need about one
+// Gaussian into one 48-byte "splat record" (three float4, 16-byte aligned) so
+// that the per-tile gather is three 16-byte loads from one or two cache lines:
+//   q0 = (mean_x, mean_y, conic_a, conic_b)
+//   q1 = (conic_d, opacity, depth, rect_x)     rect_x = x_min | x_max << 16
+//   q2 = (red, green, blue, rect_y)            rect_y = y_min | y_max << 16
+// conic = inverse of the 2x2 screen covariance, [[a,b],[b,d]]; rect is the
+// reference's hard integer 3-sigma box (:393-399), half-open, clipped to the image.
+//
+// The backward per-Gaussian gradient rows are 16 floats (64 B, one atomic
+// request per row segment):
+//   [0] d mean_x  [1] d mean_y  [2] d conic_a  [3] d conic_b (each off-diagonal entry)
+//   [4] d conic_d [5] d opacity [6..8] d rgb   [9] d depth   [10..15] unused
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GS_TILE 16          // tile edge in pixels (keys, ranges)
+#define GS_SUB 8            // one wave64 owns an 8x8 sub-tile
+#define GS_BLOCK 256        // threads per tile workgroup = 4 waves
+#define GS_GRAD_ROW 16      // floats per gradient row
+
+#define GS_OK 0
+#define GS_ERR_ARG (-1)
+#define GS_ERR_HIP (-2)
+#define GS_ERR_SIZE (-3)
+
+void gs_set_error(const char* fmt, ...);
+
+#define GS_CHECK_HIP(expr)                                                          \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            gs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                         __FILE__, __LINE__);                                       \
+            return GS_ERR_HIP;                                                      \
+        }                                                                           \
+    } while (0)
+
+#define GS_CHECK_LAUNCH(name)                                                       \
+    do {                                                                            \
+        hipError_t _e = hipGetLastError();                                          \
+        if (_e != hipSuccess) {                                                     \
+            gs_set_error("launch of %s failed: %s", name, hipGetErrorString(_e));   \
+            return GS_ERR_HIP;                                                      \
+        }                                                                           \
+    } while (0)
+
+#define GS_REQUIRE(cond, ...)                                                       \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            gs_set_error(__VA_ARGS__);                                              \
+            return GS_ERR_ARG;                                                      \
+        }                                                                           \
+    } while (0)
+
+static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// depth -> 32-bit key whose ascending order is descending depth
+__device__ __forceinline__ uint32_t gs_depth_key_desc(float z) {
+    z = z + 0.0f;  // -0 -> +0
+    uint32_t u = __float_as_uint(z);
+    uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~asc;
+}

@@ -1,0 +1,564 @@
+// Per-Gaussian stage, forward and backward: one lane per Gaussian.
+//
+// Forward restates (arithmetic of) reference gaussian_renderer/__init__.py:
+//   :116-133 homogeneous transforms + NDC -> pixel, :210-264 / :266-289 Sigma,
+//   :291-334 J Sigma J^T + 0.3 I, :185-208 + utils/sh_utils.py:40-96 SH colour with the
+//   two-sided clamp, and the per-Gaussian tests of splat_gaussians :368-402
+//   (+-50 px guard, det < 1e-7, hard integer 3-sigma box).
+// Backward is the reverse-mode derivative of those lines (autograd in the reference).
+//
+// The geometry part is compiled with fp contraction OFF and correctly rounded
+// divide/sqrt (hipcc default), in the same operation order as oracle/gs_oracle.c, so the
+// integer outputs (rect, radii, tiles_touched) are bit-exact against the oracle.
+//
+// HBM-bound: algorithmic bytes per Gaussian are 40 (mean, scale, rotation) + 4 (opacity)
+// + 12 K (SH) read and 48 (record) + 8 (radii, tiles_touched) written.
+#include "gsplat_common.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f;
+constexpr float SH_C2_1 = -1.0925484305920792f;
+constexpr float SH_C2_2 = 0.3153915652525205f;
+constexpr float SH_C2_3 = -1.0925484305920792f;
+constexpr float SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f;
+constexpr float SH_C3_1 = 2.890611442640554f;
+constexpr float SH_C3_2 = -0.4570457994644658f;
+constexpr float SH_C3_3 = 0.3731763325901154f;
+constexpr float SH_C3_4 = -0.4570457994644658f;
+constexpr float SH_C3_5 = 1.445305721320277f;
+constexpr float SH_C3_6 = -0.5900435899266435f;
+
+struct Geom {
+    float cam[3];
+    float clip[4];
+    float mx, my;
+    float S[3][3];       // Sigma
+    float R[3][3];       // rotation (scale/rotation path only)
+    float j00, j02, j11, j12;
+    float c00, c01, c11;
+    float inv_det, ca, cb, cd;
+    int xmin, ymin, xmax, ymax;
+    int radius;
+    uint32_t tiles;
+    bool drawn;
+};
+
+// All of this must round exactly like oracle/gs_oracle.c::gso_preprocess.
+__device__ __forceinline__ void project_gaussian(int i, int H, int W, const float* __restrict__ view,
+                                                 const float* __restrict__ proj,
+                                                 const float* __restrict__ means3D,
+                                                 const float* __restrict__ scales,
+                                                 const float* __restrict__ rots,
+                                                 const float* __restrict__ cov6, Geom& g) {
+#pragma clang fp contract(off)
+    const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        g.cam[r] = view[4 * r] * px + view[4 * r + 1] * py + view[4 * r + 2] * pz + view[4 * r + 3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        g.clip[r] = proj[4 * r] * px + proj[4 * r + 1] * py + proj[4 * r + 2] * pz + proj[4 * r + 3];
+    const float fW = (float)W, fH = (float)H;
+    const float focal_x = proj[0] * fW / 2.0f;
+    const float focal_y = proj[5] * fH / 2.0f;
+    const float wden = g.clip[3] + 1e-7f;
+    const float ndcx = g.clip[0] / wden, ndcy = g.clip[1] / wden;
+    g.mx = ((ndcx + 1.0f) * fW - 1.0f) * 0.5f;
+    g.my = ((ndcy + 1.0f) * fH - 1.0f) * 0.5f;
+
+    if (cov6) {
+        const float* c = cov6 + 6 * (size_t)i;
+        g.S[0][0] = c[0]; g.S[0][1] = c[1]; g.S[0][2] = c[2];
+        g.S[1][0] = c[1]; g.S[1][1] = c[3]; g.S[1][2] = c[4];
+        g.S[2][0] = c[2]; g.S[2][1] = c[4]; g.S[2][2] = c[5];
+    } else {
+        const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        g.R[0][0] = 1.0f - 2.0f * (y * y + z * z);
+        g.R[0][1] = 2.0f * (x * y - r * z);
+        g.R[0][2] = 2.0f * (x * z + r * y);
+        g.R[1][0] = 2.0f * (x * y + r * z);
+        g.R[1][1] = 1.0f - 2.0f * (x * x + z * z);
+        g.R[1][2] = 2.0f * (y * z - r * x);
+        g.R[2][0] = 2.0f * (x * z - r * y);
+        g.R[2][1] = 2.0f * (y * z + r * x);
+        g.R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+        const float s0 = scales[3 * (size_t)i], s1 = scales[3 * (size_t)i + 1], s2 = scales[3 * (size_t)i + 2];
+        float M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            M[a][0] = g.R[a][0] * s0;
+            M[a][1] = g.R[a][1] * s1;
+            M[a][2] = g.R[a][2] * s2;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                g.S[a][b] = M[a][0] * M[b][0] + M[a][1] * M[b][1] + M[a][2] * M[b][2];
+    }
+    const float x = g.cam[0], y = g.cam[1], z = g.cam[2];
+    g.j00 = focal_x / (z + 1e-7f);
+    g.j02 = -x * focal_x / (z * z + 1e-7f);
+    g.j11 = focal_y / (z + 1e-7f);
+    g.j12 = -y * focal_y / (z * z + 1e-7f);
+    const float t00 = g.j00 * g.S[0][0] + g.j02 * g.S[2][0];
+    const float t01 = g.j00 * g.S[0][1] + g.j02 * g.S[2][1];
+    const float t02 = g.j00 * g.S[0][2] + g.j02 * g.S[2][2];
+    const float t11 = g.j11 * g.S[1][1] + g.j12 * g.S[2][1];
+    const float t12 = g.j11 * g.S[1][2] + g.j12 * g.S[2][2];
+    g.c00 = (t00 * g.j00 + t02 * g.j02) + 0.3f;
+    g.c01 = t01 * g.j11 + t02 * g.j12;
+    g.c11 = (t11 * g.j11 + t12 * g.j12) + 0.3f;
+
+    bool drawn = true;
+    if (g.mx < -50.0f || g.mx > fW + 50.0f || g.my < -50.0f || g.my > fH + 50.0f) drawn = false;
+    const float det = g.c00 * g.c11 - g.c01 * g.c01;
+    if (det < 1e-7f) drawn = false;
+    g.inv_det = 1.0f / det;
+    g.ca = g.c11 * g.inv_det;
+    g.cb = -g.c01 * g.inv_det;
+    g.cd = g.c00 * g.inv_det;
+    const float sx = sqrtf(g.c00) * 3.0f, sy = sqrtf(g.c11) * 3.0f;
+    float lo, hi;
+    lo = g.mx - sx;        lo = (lo > 0.0f) ? lo : 0.0f;
+    hi = g.mx + sx + 1.0f; hi = (hi < fW) ? hi : fW;
+    g.xmin = (int)lo; g.xmax = (int)hi;
+    lo = g.my - sy;        lo = (lo > 0.0f) ? lo : 0.0f;
+    hi = g.my + sy + 1.0f; hi = (hi < fH) ? hi : fH;
+    g.ymin = (int)lo; g.ymax = (int)hi;
+    if (g.xmin >= g.xmax || g.ymin >= g.ymax) drawn = false;
+    g.drawn = drawn;
+    if (!drawn) {
+        g.xmin = g.ymin = g.xmax = g.ymax = 0;
+        g.radius = 0;
+        g.tiles = 0;
+    } else {
+        const float m = (sx > sy) ? sx : sy;
+        g.radius = (m >= 1.0f && m < 32767.0f) ? (int)ceilf(m) : (m >= 32767.0f ? 32767 : 1);
+        const int tx0 = g.xmin / GS_TILE, tx1 = (g.xmax - 1) / GS_TILE + 1;
+        const int ty0 = g.ymin / GS_TILE, ty1 = (g.ymax - 1) / GS_TILE + 1;
+        g.tiles = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
+    }
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+    b[0] = SH_C0;
+    if (DEG > 0) {
+        b[1] = -SH_C1 * y;
+        b[2] = SH_C1 * z;
+        b[3] = -SH_C1 * x;
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = SH_C2_0 * xy;
+        b[5] = SH_C2_1 * yz;
+        b[6] = SH_C2_2 * (2.0f * zz - xx - yy);
+        b[7] = SH_C2_3 * xz;
+        b[8] = SH_C2_4 * (xx - yy);
+        if (DEG > 2) {
+            b[9] = SH_C3_0 * y * (3.0f * xx - yy);
+            b[10] = SH_C3_1 * xy * z;
+            b[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+            b[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            b[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+            b[14] = SH_C3_5 * z * (xx - yy);
+            b[15] = SH_C3_6 * x * (xx - 3.0f * yy);
+        }
+    }
+}
+
+// d basis_k / d(x,y,z)
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float (*g)[3]) {
+    g[0][0] = g[0][1] = g[0][2] = 0.0f;
+    if (DEG > 0) {
+        g[1][0] = 0; g[1][1] = -SH_C1; g[1][2] = 0;
+        g[2][0] = 0; g[2][1] = 0; g[2][2] = SH_C1;
+        g[3][0] = -SH_C1; g[3][1] = 0; g[3][2] = 0;
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        g[4][0] = SH_C2_0 * y; g[4][1] = SH_C2_0 * x; g[4][2] = 0;
+        g[5][0] = 0; g[5][1] = SH_C2_1 * z; g[5][2] = SH_C2_1 * y;
+        g[6][0] = SH_C2_2 * -2.0f * x; g[6][1] = SH_C2_2 * -2.0f * y; g[6][2] = SH_C2_2 * 4.0f * z;
+        g[7][0] = SH_C2_3 * z; g[7][1] = 0; g[7][2] = SH_C2_3 * x;
+        g[8][0] = SH_C2_4 * 2.0f * x; g[8][1] = SH_C2_4 * -2.0f * y; g[8][2] = 0;
+        if (DEG > 2) {
+            g[9][0] = SH_C3_0 * 6.0f * xy; g[9][1] = SH_C3_0 * (3.0f * xx - 3.0f * yy); g[9][2] = 0;
+            g[10][0] = SH_C3_1 * yz; g[10][1] = SH_C3_1 * xz; g[10][2] = SH_C3_1 * xy;
+            g[11][0] = SH_C3_2 * -2.0f * xy; g[11][1] = SH_C3_2 * (4.0f * zz - xx - 3.0f * yy);
+            g[11][2] = SH_C3_2 * 8.0f * yz;
+            g[12][0] = SH_C3_3 * -6.0f * xz; g[12][1] = SH_C3_3 * -6.0f * yz;
+            g[12][2] = SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+            g[13][0] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); g[13][1] = SH_C3_4 * -2.0f * xy;
+            g[13][2] = SH_C3_4 * 8.0f * xz;
+            g[14][0] = SH_C3_5 * 2.0f * xz; g[14][1] = SH_C3_5 * -2.0f * yz; g[14][2] = SH_C3_5 * (xx - yy);
+            g[15][0] = SH_C3_6 * (3.0f * xx - 3.0f * yy); g[15][1] = SH_C3_6 * -6.0f * xy; g[15][2] = 0;
+        }
+    }
+}
+
+// loads the first NB coefficient triples of Gaussian i; VEC4: rows are 16-byte aligned multiples of 16 B
+template <int NB, bool VEC4>
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int i, int K, float* sh) {
+    const float* p = shs + (size_t)i * K * 3;
+    if (VEC4) {
+        constexpr int NV = (NB * 3 + 3) / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 t = p4[v];
+            if (4 * v + 0 < NB * 3) sh[4 * v + 0] = t.x;
+            if (4 * v + 1 < NB * 3) sh[4 * v + 1] = t.y;
+            if (4 * v + 2 < NB * 3) sh[4 * v + 2] = t.z;
+            if (4 * v + 3 < NB * 3) sh[4 * v + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) sh[k] = p[k];
+    }
+}
+
+template <int DEG, bool VEC4>
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+    int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ campos, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ cov6, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Geom g;
+    project_gaussian(i, H, W, view, proj, means3D, scales, rots, cov6, g);
+    radii[i] = g.radius;
+    tiles_touched[i] = g.tiles;
+    if (!g.drawn) return;
+    float rgb[3];
+    if (colors_precomp) {
+        rgb[0] = colors_precomp[3 * (size_t)i];
+        rgb[1] = colors_precomp[3 * (size_t)i + 1];
+        rgb[2] = colors_precomp[3 * (size_t)i + 2];
+    } else {
+        constexpr int NB = (DEG + 1) * (DEG + 1);
+        float sh[NB * 3 + 3], b[NB];
+        load_sh<NB, VEC4>(shs, i, K, sh);
+        float dx = means3D[3 * (size_t)i] - campos[0];
+        float dy = means3D[3 * (size_t)i + 1] - campos[1];
+        float dz = means3D[3 * (size_t)i + 2] - campos[2];
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-7f;
+        dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
+        sh_basis<DEG>(dx, dy, dz, b);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v += b[k] * sh[3 * k + c];
+            v += 0.5f;
+            rgb[c] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+    }
+    const uint32_t rx = (uint32_t)g.xmin | ((uint32_t)g.xmax << 16);
+    const uint32_t ry = (uint32_t)g.ymin | ((uint32_t)g.ymax << 16);
+    float4* o = splat + 3 * (size_t)i;
+    o[0] = make_float4(g.mx, g.my, g.ca, g.cb);
+    o[1] = make_float4(g.cd, opacities[i], g.cam[2], __uint_as_float(rx));
+    o[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(ry));
+}
+
+template <int DEG, bool VEC4>
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+    int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ campos, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ cov6, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const int32_t* __restrict__ radii,
+    const float4* __restrict__ grad_rows, float* __restrict__ g_means3D,
+    float* __restrict__ g_means2D, float* __restrict__ g_scales, float* __restrict__ g_rots,
+    float* __restrict__ g_cov6, float* __restrict__ g_opac, float* __restrict__ g_shs,
+    float* __restrict__ g_colors) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const bool drawn = radii[i] > 0;
+    float gm[3] = {0.f, 0.f, 0.f};
+    float gm2[2] = {0.f, 0.f};
+    float gs[3] = {0.f, 0.f, 0.f};
+    float gq[4] = {0.f, 0.f, 0.f, 0.f};
+    float gc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gop = 0.f;
+    float gcol[3] = {0.f, 0.f, 0.f};
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float* gsh_out = g_shs ? g_shs + (size_t)i * K * 3 : nullptr;
+    int sh_written = 0;
+    if (drawn) {
+        Geom g;
+        project_gaussian(i, H, W, view, proj, means3D, scales, rots, cov6, g);
+        const float4 r0 = grad_rows[4 * (size_t)i], r1 = grad_rows[4 * (size_t)i + 1],
+                     r2 = grad_rows[4 * (size_t)i + 2];
+        const float d_mx = r0.x, d_my = r0.y, d_a = r0.z, d_b = r0.w;
+        const float d_d = r1.x, d_op = r1.y, d_r = r1.z, d_g = r1.w;
+        const float d_bl = r2.x, d_z = r2.y;
+        gop = d_op;
+        gm2[0] = d_mx;
+        gm2[1] = d_my;
+        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        // ---- colour
+        if (colors_precomp) {
+            gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
+        } else if (shs) {
+            float sh[NB * 3 + 3], b[NB], bg[NB][3];
+            load_sh<NB, VEC4>(shs, i, K, sh);
+            const float vx = px - campos[0], vy = py - campos[1], vz = pz - campos[2];
+            const float n = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float ne = n + 1e-7f;
+            const float dx = vx / ne, dy = vy / ne, dz = vz / ne;
+            sh_basis<DEG>(dx, dy, dz, b);
+            sh_basis_grad<DEG>(dx, dy, dz, bg);
+            const float dcol[3] = {d_r, d_g, d_bl};
+            float gcl[3];
+            float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) v += b[k] * sh[3 * k + c];
+                v += 0.5f;
+                gcl[c] = (v >= 0.0f && v <= 1.0f) ? dcol[c] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float sg = sh[3 * k + c] * gcl[c];
+                    ddir[0] += bg[k][0] * sg;
+                    ddir[1] += bg[k][1] * sg;
+                    ddir[2] += bg[k][2] * sg;
+                }
+            }
+            if (gsh_out) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    gsh_out[3 * k + 0] = b[k] * gcl[0];
+                    gsh_out[3 * k + 1] = b[k] * gcl[1];
+                    gsh_out[3 * k + 2] = b[k] * gcl[2];
+                }
+                sh_written = NB * 3;
+            }
+            if (n > 0.0f) {
+                const float dot = ddir[0] * vx + ddir[1] * vy + ddir[2] * vz;
+                const float k2 = dot / (ne * ne * n);
+                gm[0] += ddir[0] / ne - vx * k2;
+                gm[1] += ddir[1] / ne - vy * k2;
+                gm[2] += ddir[2] / ne - vz * k2;
+            } else {
+                gm[0] += ddir[0] / ne; gm[1] += ddir[1] / ne; gm[2] += ddir[2] / ne;
+            }
+        }
+        // ---- screen mean
+        {
+            const float wden = g.clip[3] + 1e-7f;
+            const float dnx = 0.5f * (float)W * d_mx, dny = 0.5f * (float)H * d_my;
+            const float dcx = dnx / wden, dcy = dny / wden;
+            const float dcw = -(dnx * g.clip[0] + dny * g.clip[1]) / (wden * wden);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gm[c] += proj[c] * dcx + proj[4 + c] * dcy + proj[12 + c] * dcw;
+        }
+        // ---- conic -> cov2D
+        const float d_inv_det = d_a * g.c11 - 2.0f * d_b * g.c01 + d_d * g.c00;
+        const float d_det = -g.inv_det * g.inv_det * d_inv_det;
+        float G2[2][2];
+        G2[0][0] = d_d * g.inv_det + d_det * g.c11;
+        G2[1][1] = d_a * g.inv_det + d_det * g.c00;
+        G2[0][1] = -d_b * g.inv_det - d_det * g.c01;
+        G2[1][0] = G2[0][1];
+        // ---- cov2D = J Sigma J^T
+        const float J[2][3] = {{g.j00, 0.0f, g.j02}, {0.0f, g.j11, g.j12}};
+        float dS[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) {
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) v += J[r][a] * G2[r][c] * J[c][b2];
+                dS[a][b2] = v;
+            }
+        float JS[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                JS[r][c] = J[r][0] * g.S[0][c] + J[r][1] * g.S[1][c] + J[r][2] * g.S[2][c];
+        float dJ[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                dJ[r][c] = (G2[r][0] + G2[0][r]) * JS[0][c] + (G2[r][1] + G2[1][r]) * JS[1][c];
+        const float focal_x = proj[0] * (float)W / 2.0f, focal_y = proj[5] * (float)H / 2.0f;
+        const float x = g.cam[0], y = g.cam[1], z = g.cam[2];
+        const float zi = z + 1e-7f, z2 = z * z + 1e-7f;
+        float dcam[3];
+        dcam[0] = dJ[0][2] * (-focal_x / z2);
+        dcam[1] = dJ[1][2] * (-focal_y / z2);
+        dcam[2] = dJ[0][0] * (-focal_x / (zi * zi)) + dJ[1][1] * (-focal_y / (zi * zi)) +
+                  dJ[0][2] * (x * focal_x * 2.0f * z / (z2 * z2)) +
+                  dJ[1][2] * (y * focal_y * 2.0f * z / (z2 * z2)) + d_z;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            gm[c] += view[c] * dcam[0] + view[4 + c] * dcam[1] + view[8 + c] * dcam[2];
+        if (cov6) {
+            gc6[0] = dS[0][0]; gc6[1] = dS[0][1] + dS[1][0]; gc6[2] = dS[0][2] + dS[2][0];
+            gc6[3] = dS[1][1]; gc6[4] = dS[1][2] + dS[2][1]; gc6[5] = dS[2][2];
+        } else {
+            const float s[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+            float dR[3][3];
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) {
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) v += (dS[a][k] + dS[k][a]) * (g.R[k][b2] * s[b2]);
+                    acc += v * g.R[a][b2];
+                    dR[a][b2] = v * s[b2];
+                }
+                gs[b2] = acc;
+            }
+            const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+            const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+            gq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+            gq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - r * dR[1][2] + qz * dR[2][0] + r * dR[2][1] - 2.0f * qx * dR[2][2]);
+            gq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + r * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
+            gq[3] = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+        }
+    }
+    if (g_means3D) { g_means3D[3 * (size_t)i] = gm[0]; g_means3D[3 * (size_t)i + 1] = gm[1]; g_means3D[3 * (size_t)i + 2] = gm[2]; }
+    if (g_means2D) {
+        // densification statistic: gradient w.r.t. the NDC-scaled screen mean (pixels * W/2, H/2)
+        g_means2D[3 * (size_t)i] = gm2[0] * 0.5f * (float)W;
+        g_means2D[3 * (size_t)i + 1] = gm2[1] * 0.5f * (float)H;
+        g_means2D[3 * (size_t)i + 2] = 0.0f;
+    }
+    if (g_scales) { g_scales[3 * (size_t)i] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2]; }
+    if (g_rots) *reinterpret_cast<float4*>(g_rots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    if (g_cov6) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_cov6[6 * (size_t)i + k] = gc6[k];
+    }
+    if (g_opac) g_opac[i] = gop;
+    if (g_colors) { g_colors[3 * (size_t)i] = gcol[0]; g_colors[3 * (size_t)i + 1] = gcol[1]; g_colors[3 * (size_t)i + 2] = gcol[2]; }
+    if (gsh_out)
+        for (int k = sh_written; k < K * 3; ++k) gsh_out[k] = 0.0f;
+}
+
+template <int DEG>
+int launch_fwd(bool vec4, int N, int K, int H, int W, const float* view, const float* proj,
+               const float* campos, const float* means3D, const float* scales, const float* rots,
+               const float* cov6, const float* opac, const float* shs, const float* colors,
+               float4* splat, int32_t* radii, uint32_t* tiles, hipStream_t stream) {
+    const dim3 grid(gs_div_up(N, 256)), block(256);
+    if (vec4)
+        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, view, proj,
+                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles);
+    else
+        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, view, proj,
+                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles);
+    GS_CHECK_LAUNCH("preprocess_fwd");
+    return GS_OK;
+}
+
+template <int DEG>
+int launch_bwd(bool vec4, int N, int K, int H, int W, const float* view, const float* proj,
+               const float* campos, const float* means3D, const float* scales, const float* rots,
+               const float* cov6, const float* shs, const float* colors, const int32_t* radii,
+               const float4* rows, float* g_means3D, float* g_means2D, float* g_scales, float* g_rots,
+               float* g_cov6, float* g_opac, float* g_shs, float* g_colors, hipStream_t stream) {
+    const dim3 grid(gs_div_up(N, 256)), block(256);
+    if (vec4)
+        hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, view, proj,
+                           campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D,
+                           g_means2D, g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors);
+    else
+        hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, view, proj,
+                           campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D,
+                           g_means2D, g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors);
+    GS_CHECK_LAUNCH("preprocess_bwd");
+    return GS_OK;
+}
+
+int check_common(int N, int K, int deg, int H, int W, const void* means3D, const void* scales,
+                 const void* rots, const void* cov6, const void* shs, const void* colors) {
+    GS_REQUIRE(N >= 0, "N must be >= 0");
+    GS_REQUIRE(H > 0 && W > 0 && H < 65536 && W < 65536, "image size %dx%d outside 1..65535", W, H);
+    GS_REQUIRE(deg >= 0 && deg <= 3, "sh_degree %d outside 0..3", deg);
+    GS_REQUIRE(N == 0 || means3D, "means3D is null");
+    GS_REQUIRE((shs != nullptr) != (colors != nullptr), "exactly one of shs / colors_precomp must be given");
+    GS_REQUIRE(!shs || (deg + 1) * (deg + 1) <= K, "shs has K=%d coefficients, sh_degree %d needs %d", K, deg,
+               (deg + 1) * (deg + 1));
+    GS_REQUIRE((cov6 != nullptr) != (scales != nullptr && rots != nullptr),
+               "exactly one of (scales, rotations) / cov3D_precomp must be given");
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, const float* means3D,
+                                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                                 const float* opacities, const float* shs, const float* colors_precomp,
+                                 void* splat, int32_t* radii, uint32_t* tiles_touched, void* stream_) {
+    if (N == 0) return GS_OK;
+    int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
+    if (rc) return rc;
+    GS_REQUIRE(viewmatrix && projmatrix && campos && opacities && splat && radii && tiles_touched, "null argument");
+    GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
+    GS_REQUIRE(((uintptr_t)splat & 15) == 0, "splat buffer must be 16-byte aligned");
+    if (N == 0) return GS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0);
+    const int deg = shs ? sh_degree : 0;
+    float4* sp = (float4*)splat;
+    switch (deg) {
+        case 0: return launch_fwd<0>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        case 1: return launch_fwd<1>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        case 2: return launch_fwd<2>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        default: return launch_fwd<3>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+    }
+}
+
+extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, const float* means3D,
+                                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                                 const float* shs, const float* colors_precomp, const int32_t* radii,
+                                 const float* grad_rows, float* g_means3D, float* g_means2D,
+                                 float* g_scales, float* g_rotations, float* g_cov3D, float* g_opacities,
+                                 float* g_shs, float* g_colors, void* stream_) {
+    if (N == 0) return GS_OK;
+    int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
+    if (rc) return rc;
+    GS_REQUIRE(viewmatrix && projmatrix && campos && radii && grad_rows, "null argument");
+    GS_REQUIRE(((uintptr_t)grad_rows & 15) == 0, "grad_rows must be 16-byte aligned");
+    GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
+    GS_REQUIRE(!g_rotations || ((uintptr_t)g_rotations & 15) == 0, "g_rotations must be 16-byte aligned");
+    if (N == 0) return GS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0);
+    const int deg = shs ? sh_degree : 0;
+    const float4* rows = (const float4*)grad_rows;
+    switch (deg) {
+        case 0: return launch_bwd<0>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        case 1: return launch_bwd<1>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        case 2: return launch_bwd<2>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        default: return launch_bwd<3>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+    }
+}

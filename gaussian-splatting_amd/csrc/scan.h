@@ -1,0 +1,9 @@
+// Internal: device-wide exclusive scan used by the binning stage and the radix sort.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+size_t gs_scan_ws_bytes(long long n);
+int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32_t* total_out, void* ws,
+                          hipStream_t stream);

@@ -1,0 +1,289 @@
+"""Host side of the MI355X Gaussian rasterizer: the reference's operator interface on top of the C-ABI.
+
+Mirrors the two classes the reference imports from ``diff_gaussian_rasterization``
+(reference gaussian_renderer/__init__.py:19-27) and calls at :563-638:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug
+                                  [, antialiasing])
+    GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                        rotations, cov3D_precomp)  ->  (image, radii, depth, alpha)
+
+Semantics are those of the reference's built-in rasterizer (:64-442), which is the parity oracle:
+``tanfovx/tanfovy/scale_modifier/prefiltered/debug/antialiasing`` are stored but unused there
+ and therefore here too.
+
+PyTorch is used for device memory, the current stream and autograd plumbing only; every stage
+runs in libgsplat_hip.so (hand-written HIP for gfx950).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+TILE = 16
+GRAD_ROW = 16
+
+# Per-pixel stop threshold on the transmittance 1 - alpha_acc (see csrc/render.hip).  0.0 disables
+# it (bit-for-bit the reference's "no early termination"); what is dropped at the default is at
+# most 1e-6 * (sum of remaining alpha*colour), far below the stated 1e-4 image tolerance.
+DEFAULT_T_EPS = 1e-6
+
+
+class GaussianRasterizationSettings:
+    """Value holder with the fields of reference gaussian_renderer/__init__.py:30-61 (+ antialiasing, :576)."""
+
+    def __init__(self, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+                 projmatrix, sh_degree, campos, prefiltered, debug, antialiasing=False):
+        self.image_height = int(image_height)
+        self.image_width = int(image_width)
+        self.tanfovx = tanfovx
+        self.tanfovy = tanfovy
+        self.bg = bg
+        self.scale_modifier = scale_modifier
+        self.viewmatrix = viewmatrix
+        self.projmatrix = projmatrix
+        self.sh_degree = int(sh_degree)
+        self.campos = campos
+        self.prefiltered = prefiltered
+        self.debug = debug
+        self.antialiasing = antialiasing
+
+
+class BinningState(NamedTuple):
+    """Everything the forward leaves in HBM for the backward / for inspection."""
+    splat: torch.Tensor          # (N,12) f32 splat records (see csrc/gsplat_common.h)
+    radii: torch.Tensor          # (N,) i32
+    tiles_touched: torch.Tensor  # (N,) u32 as i32 storage
+    offsets: torch.Tensor        # (N,) exclusive scan
+    num_pairs: int               # D
+    keys: torch.Tensor           # (D,) sorted 64-bit keys (int64 storage)
+    point_list: torch.Tensor     # (D,) Gaussian index per sorted pair (int32 storage)
+    ranges: torch.Tensor         # (tiles,2) i32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prep(t: Optional[torch.Tensor], name: str, shape_tail, device) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); this back-end has no CPU path")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected (N,{','.join(map(str, shape_tail))})")
+    return t.contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _camera_tensor(t, n, name, device):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t, dtype=torch.float32)
+    t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+    if t.numel() != n:
+        raise ValueError(f"{name} must have {n} elements (got {tuple(t.shape)})")
+    return t
+
+
+def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
+                       cov3D_precomp, shs, colors_precomp) -> BinningState:
+    """preprocess -> scan -> duplicate_with_keys -> radix sort -> tile ranges (all on the current stream)."""
+    lib = _lib.load()
+    dev = means3D.device
+    N = means3D.shape[0]
+    H, W = settings.image_height, settings.image_width
+    K = shs.shape[1] if shs is not None else 0
+    view = _camera_tensor(settings.viewmatrix, 16, "viewmatrix", dev)
+    proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
+    campos = _camera_tensor(settings.campos, 3, "campos", dev)
+    st = _stream()
+    i32 = dict(dtype=torch.int32, device=dev)
+    splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
+    radii = torch.empty((N,), **i32)
+    tiles_touched = torch.empty((N,), **i32)
+    _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
+                                     _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                     _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
+                                     _ptr(radii), _ptr(tiles_touched), st), "gs_preprocess_fwd")
+    offsets = torch.empty((N,), **i32)
+    total = torch.empty((1,), **i32)
+    scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
+    host_total = C.c_uint32(0)
+    _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(offsets), _ptr(total), _ptr(scan_ws),
+                                 C.byref(host_total), st), "gs_scan_tiles")
+    D = int(host_total.value)
+    tiles_x, tiles_y = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    ntiles = tiles_x * tiles_y
+    keys_a = torch.empty((max(D, 1),), dtype=torch.int64, device=dev)
+    keys_b = torch.empty((max(D, 1),), dtype=torch.int64, device=dev)
+    vals_a = torch.empty((max(D, 1),), **i32)
+    vals_b = torch.empty((max(D, 1),), **i32)
+    _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(offsets), _ptr(tiles_touched),
+                                          _ptr(keys_a), _ptr(vals_a), st), "gs_duplicate_with_keys")
+    bits = 32 + max(1, (ntiles - 1).bit_length())
+    ws_bytes = lib.gs_sort_workspace_bytes(D)
+    sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
+    in_b = C.c_int(0)
+    _lib.check(lib.gs_sort_pairs(D, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+                                 _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
+    keys, point_list = (keys_b, vals_b) if in_b.value else (keys_a, vals_a)
+    ranges = torch.empty((ntiles, 2), **i32)
+    _lib.check(lib.gs_identify_tile_ranges(D, ntiles, _ptr(keys), _ptr(ranges), st), "gs_identify_tile_ranges")
+    return BinningState(splat, radii, tiles_touched, offsets, D, keys[:D], point_list[:D], ranges)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                settings, t_eps):
+        lib = _lib.load()
+        dev = means3D.device
+        H, W = settings.image_height, settings.image_width
+        bg = _camera_tensor(settings.bg, 3, "bg", dev)
+        with torch.cuda.device(dev):
+            state = preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                       colors_precomp)
+            need_grad = any(t is not None and t.requires_grad for t in
+                            (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
+            image = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            aux = torch.empty((3, H, W), dtype=torch.float32, device=dev) if need_grad else None
+            _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(state.splat), _ptr(state.ranges),
+                                         _ptr(state.point_list), _ptr(image), _ptr(depth), _ptr(alpha),
+                                         _ptr(aux), float(t_eps), _stream()), "gs_render_fwd")
+        ctx.settings = settings
+        ctx.t_eps = float(t_eps)
+        ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
+        ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
+        saved = [means3D, opacities, state.splat, state.radii, state.point_list, state.ranges, depth, alpha]
+        saved += [t for t in (shs, colors_precomp, scales, rotations, cov3D_precomp) if t is not None]
+        if aux is not None:
+            saved.append(aux)
+        ctx.has_aux = aux is not None
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(state.radii)
+        return image, state.radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_image, g_radii, g_depth, g_alpha):
+        lib = _lib.load()
+        saved = list(ctx.saved_tensors)
+        means3D, opacities, splat, radii, point_list, ranges, depth, alpha = saved[:8]
+        rest = saved[8:]
+        opt = []
+        for h in ctx.has:
+            opt.append(rest.pop(0) if h else None)
+        shs, colors_precomp, scales, rotations, cov3D_precomp = opt
+        if not ctx.has_aux:
+            raise RuntimeError("backward called but no input required grad in forward")
+        aux = rest.pop(0)
+        settings = ctx.settings
+        dev = means3D.device
+        N = means3D.shape[0]
+        H, W = settings.image_height, settings.image_width
+        K = shs.shape[1] if shs is not None else 0
+        view = _camera_tensor(settings.viewmatrix, 16, "viewmatrix", dev)
+        proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
+        campos = _camera_tensor(settings.campos, 3, "campos", dev)
+
+        def gin(t, shape):
+            if t is None:
+                return None
+            return t.to(torch.float32).expand(shape).contiguous()
+
+        with torch.cuda.device(dev):
+            st = _stream()
+            g_image = gin(g_image, (3, H, W))
+            if g_image is None:
+                g_image = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+            g_depth = gin(g_depth, (1, H, W))
+            g_alpha = gin(g_alpha, (1, H, W))
+            rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
+            _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux),
+                                         _ptr(depth), _ptr(alpha), _ptr(g_image), _ptr(g_depth),
+                                         _ptr(g_alpha), _ptr(rows), ctx.t_eps, st), "gs_render_bwd")
+            needs = ctx.needs_input_grad
+            f32 = dict(dtype=torch.float32, device=dev)
+            g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
+            g_means2D = torch.empty(ctx.means2D_shape, **f32) if (needs[1] and ctx.means2D_shape == (N, 3)) else None
+            g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
+            g_colors = torch.empty((N, 3), **f32) if (colors_precomp is not None and needs[3]) else None
+            g_opac = torch.empty_like(opacities) if needs[4] else None
+            g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
+            g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
+            g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
+            _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
+                                             _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                             _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
+                                             _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
+                                             _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors), st),
+                       "gs_preprocess_bwd")
+        if needs[1] and g_means2D is None and ctx.means2D_shape is not None:
+            g_means2D = torch.zeros(ctx.means2D_shape, **f32)
+        return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov, None, None
+
+
+def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                        raster_settings, t_eps: float = DEFAULT_T_EPS):
+    return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                     cov3D_precomp, raster_settings, t_eps)
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for the class the reference constructs at gaussian_renderer/__init__.py:585 and calls at :635."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings, t_eps: float = DEFAULT_T_EPS):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self.t_eps = t_eps
+
+    def forward(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
+                rotations=None, cov3D_precomp=None, cov3Ds_precomp=None):
+        rs = self.raster_settings
+        if cov3D_precomp is None:
+            cov3D_precomp = cov3Ds_precomp          # the reference's own spelling (:85, :637)
+        if (shs is None) == (colors_precomp is None):
+            raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if opacities is None:
+            raise ValueError("opacities is required")
+        if not torch.is_tensor(means3D) or means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise ValueError("means3D must be a (N,3) tensor")
+        dev = means3D.device
+        N = means3D.shape[0]
+        means3D = _prep(means3D, "means3D", (3,), dev)
+        if shs is not None:
+            if shs.dim() != 3 or shs.shape[2] != 3:
+                raise ValueError(f"shs must be (N,K,3), got {tuple(shs.shape)}")
+            if (rs.sh_degree + 1) ** 2 > shs.shape[1]:
+                raise ValueError(f"sh_degree {rs.sh_degree} needs {(rs.sh_degree + 1) ** 2} coefficients, shs has {shs.shape[1]}")
+            shs = _prep(shs, "shs", None, dev)
+        colors_precomp = _prep(colors_precomp, "colors_precomp", (3,), dev)
+        opacities = _prep(opacities.reshape(N, 1) if opacities.dim() == 1 else opacities, "opacities", (1,), dev)
+        scales = _prep(scales, "scales", (3,), dev)
+        rotations = _prep(rotations, "rotations", (4,), dev)
+        cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", (6,), dev)
+        for name, t in (("shs", shs), ("colors_precomp", colors_precomp), ("opacities", opacities),
+                        ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp)):
+            if t is not None and t.shape[0] != N:
+                raise ValueError(f"{name} has {t.shape[0]} rows, means3D has {N}")
+        if not (0 <= rs.sh_degree <= 3):
+            raise ValueError(f"sh_degree must be 0..3, got {rs.sh_degree}")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs, self.t_eps)

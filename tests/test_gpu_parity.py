@@ -1,0 +1,211 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the drop-in package) against
+ (a) the golden vectors recorded from the reference's PyTorch rasterizer, and
+ (b) the CPU oracle (oracle/gs_oracle.c) on the same seeded inputs,
+to the tolerances stated in tests/util.py; integer outputs (radii, tiles_touched, boxes, keys,
+sorted order, tile ranges) bit-exact against the oracle.
+
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from util import (TOL_DEPTH, TOL_IMAGE, check_grad, check_image, golden_inputs, golden_names, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_names()
+
+
+@pytest.fixture(scope="module")
+def dgr():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import diff_gaussian_rasterization as m
+    return m
+
+
+def _settings(dgr, g, dev):
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    return dgr.GaussianRasterizationSettings(
+        image_height=int(g["H"]), image_width=int(g["W"]), tanfovx=float(g["tanfovx"]),
+        tanfovy=float(g["tanfovy"]), bg=t(g["bg"]), scale_modifier=1.0, viewmatrix=t(g["viewmatrix"]),
+        projmatrix=t(g["projmatrix"]), sh_degree=int(g["sh_degree"]), campos=t(g["campos"]),
+        prefiltered=False, debug=False, antialiasing=False)
+
+
+def _run_hip(dgr, g, t_eps, G=None):
+    """The reference adapter's call pattern (gaussian_renderer/__init__.py:585-638) on golden inputs."""
+    dev = torch.device("cuda:0")
+    inp = {k: (None if v is None else torch.tensor(v, device=dev, requires_grad=True))
+           for k, v in golden_inputs(g).items()}
+    rast = dgr.GaussianRasterizer(raster_settings=_settings(dgr, g, dev), t_eps=t_eps)
+    means2D = torch.zeros_like(inp["means3D"], requires_grad=True, device=dev) + 0
+    means2D.retain_grad()
+    out = rast(means3D=inp["means3D"], means2D=means2D, shs=inp["shs"], colors_precomp=inp["colors_precomp"],
+               opacities=inp["opacities"], scales=inp["scales"], rotations=inp["rotations"],
+               cov3D_precomp=inp["cov3D_precomp"])
+    assert isinstance(out, tuple) and len(out) >= 3
+    image, radii, depth, alpha = out
+    G = G or g
+    t = lambda a: torch.as_tensor(a, device=dev)  # noqa: E731
+    loss = (image * t(G["G_C"])).sum() + (depth * t(G["G_Z"])).sum() + (alpha * t(G["G_A"])).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    return image, radii, depth, alpha, inp, means2D
+
+
+@pytest.mark.parametrize("t_eps", [0.0, 1e-6])
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_forward_backward(dgr, name, t_eps):
+    g = load_golden(name)
+    image, radii, depth, alpha, inp, means2D = _run_hip(dgr, g, t_eps)
+    check_image(name + ":render", image.detach().cpu().numpy(), g["out_render"], TOL_IMAGE)
+    check_image(name + ":alpha", alpha.detach().cpu().numpy(), g["out_alpha"], TOL_IMAGE)
+    check_image(name + ":depth", depth.detach().cpu().numpy(), g["out_depth"], TOL_DEPTH, scale=10.0)
+    for k, v in inp.items():
+        if v is not None:
+            check_grad(f"{name}:d_{k}", v.grad.cpu().numpy(), g["grad_" + k])
+    # means2D.grad = d loss / d screen mean (pixels) scaled to NDC units (x W/2, x H/2); z column 0
+    gm = means2D.grad.cpu().numpy()
+    ref = g["grad_means_screen"] * np.array([0.5 * g["W"], 0.5 * g["H"]], dtype=np.float32)
+    check_grad(name + ":d_means2D", gm[:, :2], ref)
+    assert np.all(gm[:, 2] == 0)
+    assert radii.dtype == torch.int32 and radii.shape == (g["in_means3D"].shape[0],)
+
+
+@pytest.mark.parametrize("name", ["edge_deg3", "m200_deg3_seed1", "camera_render_deg0", "cov3dprecomp_deg3"])
+def test_integer_stage_bit_exact_vs_oracle(dgr, oracle, name):
+    g = load_golden(name)
+    dev = torch.device("cuda:0")
+    inp = golden_inputs(g)
+    geom = oracle.preprocess(g["H"], g["W"], g["sh_degree"], g["viewmatrix"], g["projmatrix"], g["campos"],
+                             **{k: v for k, v in inp.items() if k != "opacities"})
+    ob = oracle.binning(geom)
+    tin = {k: (None if v is None else torch.tensor(v, device=dev)) for k, v in inp.items()}
+    st = dgr.preprocess_and_bin(_settings(dgr, g, dev), tin["means3D"], tin["opacities"], tin["scales"],
+                                tin["rotations"], tin["cov3D_precomp"], tin["shs"], tin["colors_precomp"])
+    torch.cuda.synchronize()
+    _compare_binning(st, geom, ob)
+
+
+def _compare_binning(st, geom, ob):
+    radii = st.radii.cpu().numpy()
+    tiles = st.tiles_touched.cpu().numpy().view(np.uint32)
+    assert np.array_equal(radii, geom.radii), "radii differ"
+    assert np.array_equal(tiles, geom.tiles_touched), "tiles_touched differ"
+    drawn = tiles > 0
+    sp = st.splat.cpu().numpy()
+    bits = sp.view(np.uint32)
+    rx, ry = bits[:, 7], bits[:, 11]
+    rect = np.stack([rx & 0xFFFF, ry & 0xFFFF, rx >> 16, ry >> 16], axis=1).astype(np.int32)
+    assert np.array_equal(rect[drawn], geom.rect[drawn]), "boxes differ"
+    # the geometry is computed with identical IEEE operations -> bit-exact floats too
+    assert np.array_equal(sp[drawn, 0:2], geom.xy[drawn]), "screen means differ"
+    assert np.array_equal(sp[drawn, 6], geom.depth[drawn]), "depths differ"
+    assert np.array_equal(sp[drawn][:, [2, 3, 4]], geom.conic[drawn]), "conics differ"
+    np.testing.assert_allclose(sp[drawn, 8:11], geom.rgb[drawn], rtol=0, atol=2e-6)
+    assert np.array_equal(st.offsets.cpu().numpy().view(np.uint32), ob["offsets"]), "offsets differ"
+    assert st.num_pairs == ob["D"]
+    assert np.array_equal(st.keys.cpu().numpy().view(np.uint64), ob["keys"]), "sorted keys differ"
+    assert np.array_equal(st.point_list.cpu().numpy().view(np.uint32), ob["vals"]), "sorted values differ"
+    assert np.array_equal(st.ranges.cpu().numpy().view(np.uint32), ob["ranges"]), "tile ranges differ"
+
+
+def _scene_inputs(sc, dev):
+    return dict(means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+                rotations=sc.rotations.to(dev), shs=sc.shs.to(dev))
+
+
+def _scene_settings(dgr, sc, dev):
+    return dgr.GaussianRasterizationSettings(
+        image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=sc.bg.to(dev),
+        scale_modifier=1.0, viewmatrix=sc.viewmatrix.to(dev), projmatrix=sc.projmatrix.to(dev),
+        sh_degree=sc.sh_degree, campos=sc.campos.to(dev), prefiltered=False, debug=False)
+
+
+@pytest.mark.parametrize("N,K,H,W,seed", [(20000, 16, 300, 420, 3), (60000, 4, 203, 317, 4)])
+def test_midsize_vs_oracle(dgr, oracle, N, K, H, W, seed):
+    """Sizes the reference cannot reach in reasonable time; the pinned oracle is the checker."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    sc = syn.make_scene(N, K, H, W, seed=seed)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(99)
+    G_C = sc.G
+    G_Z = (torch.rand(1, H, W, generator=g) * 2 - 1) * 0.1
+    G_A = torch.rand(1, H, W, generator=g) * 2 - 1
+    outs, grads, geom = oracle.forward_backward(
+        H, W, sc.sh_degree, sc.viewmatrix.numpy(), sc.projmatrix.numpy(), sc.campos.numpy(), sc.bg.numpy(),
+        sc.means3D.numpy(), sc.opacities.numpy(), scales=sc.scales.numpy(), rotations=sc.rotations.numpy(),
+        shs=sc.shs.numpy(), G_C=G_C.numpy(), G_Z=G_Z.numpy(), G_A=G_A.numpy())
+    inp = {k: v.clone().requires_grad_(True) for k, v in _scene_inputs(sc, dev).items()}
+    rast = dgr.GaussianRasterizer(_scene_settings(dgr, sc, dev), t_eps=0.0)
+    means2D = torch.zeros_like(inp["means3D"], requires_grad=True)
+    image, radii, depth, alpha = rast(means3D=inp["means3D"], means2D=means2D, shs=inp["shs"],
+                                      colors_precomp=None, opacities=inp["opacities"], scales=inp["scales"],
+                                      rotations=inp["rotations"], cov3D_precomp=None)
+    ((image * G_C.to(dev)).sum() + (depth * G_Z.to(dev)).sum() + (alpha * G_A.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), geom.radii)
+    # HIP and oracle share boxes bit for bit, so no edge outliers are expected here
+    assert np.abs(image.detach().cpu().numpy() - outs["render"]).max() <= TOL_IMAGE
+    assert np.abs(alpha.detach().cpu().numpy() - outs["alpha"]).max() <= TOL_IMAGE
+    assert np.abs(depth.detach().cpu().numpy() - outs["depth"]).max() <= TOL_DEPTH
+    for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+        check_grad(f"mid:d_{k}", inp[k].grad.cpu().numpy(), grads[k])
+    st = dgr.preprocess_and_bin(_scene_settings(dgr, sc, dev), *[inp[k].detach() for k in
+                                                                 ("means3D", "opacities", "scales", "rotations")],
+                                None, inp["shs"].detach(), None)
+    torch.cuda.synchronize()
+    _compare_binning(st, geom, oracle.binning(geom))
+
+
+def test_early_stop_is_within_tolerance(dgr):
+    """Default t_eps against t_eps = 0 (the reference's exact semantics) on a dense scene."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    sc = syn.make_scene(200000, 16, 256, 256, seed=5)
+    dev = torch.device("cuda:0")
+    res = []
+    for t_eps in (0.0, dgr.DEFAULT_T_EPS):
+        inp = {k: v.clone().requires_grad_(True) for k, v in _scene_inputs(sc, dev).items()}
+        rast = dgr.GaussianRasterizer(_scene_settings(dgr, sc, dev), t_eps=t_eps)
+        image, radii, depth, alpha = rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"],
+                                          opacities=inp["opacities"], scales=inp["scales"],
+                                          rotations=inp["rotations"])
+        (image * sc.G.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        res.append((image.detach().cpu().numpy(), depth.detach().cpu().numpy(),
+                    {k: v.grad.cpu().numpy() for k, v in inp.items()}))
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-5
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-4
+    for k in res[0][2]:
+        check_grad("early_stop:d_" + k, res[1][2][k], res[0][2][k], rel=1e-4)
+
+
+def test_errors_and_edge_shapes(dgr):
+    dev = torch.device("cuda:0")
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    sc = syn.make_scene(10, 16, 33, 47, seed=0)
+    rast = dgr.GaussianRasterizer(_scene_settings(dgr, sc, dev))
+    inp = _scene_inputs(sc, dev)
+    with pytest.raises(ValueError):   # both colour sources
+        rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"], colors_precomp=torch.zeros(10, 3, device=dev),
+             opacities=inp["opacities"], scales=inp["scales"], rotations=inp["rotations"])
+    with pytest.raises(ValueError):   # neither covariance source
+        rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"])
+    with pytest.raises(RuntimeError):  # CPU tensors are refused loudly (no fallback)
+        rast(means3D=sc.means3D, means2D=None, shs=sc.shs, opacities=sc.opacities, scales=sc.scales,
+             rotations=sc.rotations)
+    # N = 0 renders the background
+    e = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    image, radii, depth, alpha = rast(means3D=e(0, 3), means2D=None, shs=e(0, 16, 3), opacities=e(0, 1),
+                                      scales=e(0, 3), rotations=e(0, 4))
+    torch.cuda.synchronize()
+    assert image.shape == (3, 33, 47) and float(image.abs().max()) == 0.0 and radii.numel() == 0
+    # the reference's own kwarg spelling is accepted (gaussian_renderer/__init__.py:637)
+    cov = torch.eye(3, device=dev).reshape(1, 9)[:, [0, 1, 2, 4, 5, 8]].repeat(10, 1) * 0.01
+    out = rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
+               cov3Ds_precomp=cov)
+    assert isinstance(out, tuple) and out[0].shape == (3, 33, 47)

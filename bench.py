@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s of rasterizer forward+backward at 3 M Gaussians, SH degree 3, 1297x840.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (preprocess -> scan -> keys -> radix sort -> ranges ->
+render forward -> render backward -> preprocess backward) over one synthetic frame per GPU
+(SURVEY.md 8d generator, config 3), inputs already resident in HBM.  With N > 1 every rank
+renders its own camera view of the same replicated Gaussians and the per-Gaussian gradients are
+summed across ranks with a bucketed RCCL all-reduce inside the timed region (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events
+on the launch stream; `cpu_baseline` is the CPU oracle (oracle/gs_oracle.c, a port -- the reference
+is a Python loop that needs ~100 min for this frame) timed on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (guides/MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # name: (N, K, H, W)
+    "config3_garden_3M_sh3_1297x840": (3_000_000, 16, 840, 1297),
+    "config2_lego_300k_sh3_800x800": (300_000, 16, 800, 800),
+    "tiny_20k_sh3_320x240": (20_000, 16, 240, 320),
+}
+
+
+def bytes_v1(N, V, D, P, K, tiles, passes):
+    """SURVEY.md 8d 'algorithmic bytes per frame', per stage."""
+    inb = 4 * (3 + 3 + 4 + 1 + 3 * K)
+    return {
+        "preprocess_fwd": 40 * N + (inb - 40) * V + 60 * V + 4 * N,
+        "scan": 8 * N,
+        "duplicate_with_keys": 24 * V + 12 * D,
+        "radix_sort": 8 * D + passes * 24 * D,
+        "identify_ranges": 8 * D + 8 * tiles,
+        "render_fwd": 60 * D + 28 * P,
+        "render_bwd": 60 * D + 32 * P + 40 * D,
+        "preprocess_bwd": (40 + inb + 60) * V + inb * N,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="config3_garden_3M_sh3_1297x840", choices=list(CONFIGS))
+    ap.add_argument("--t-eps", type=float, default=None, help="per-pixel stop threshold (default: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLW0621
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import diff_gaussian_rasterization as dgr
+    impl = importlib.import_module("gaussian-splatting_amd")
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    prof = importlib.import_module("gaussian-splatting_amd.profiling")
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+
+    N, K, H, W = CONFIGS[args.config]
+    t_eps = impl.DEFAULT_T_EPS if args.t_eps is None else args.t_eps
+    scene = syn.make_scene(N, K, H, W, seed=0)
+    view = syn.jitter_view(scene, rank) if world > 1 else scene
+    params = {k: getattr(scene, k).to(dev).requires_grad_(True)
+              for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    G = scene.G.to(dev)
+    settings = dgr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=view.tanfovx, tanfovy=view.tanfovy, bg=view.bg.to(dev),
+        scale_modifier=1.0, viewmatrix=view.viewmatrix.to(dev), projmatrix=view.projmatrix.to(dev),
+        sh_degree=view.sh_degree, campos=view.campos.to(dev), prefiltered=False, debug=False)
+    rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
+    reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20)) if world > 1 else None
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+        image, radii, depth, alpha = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                          colors_precomp=None, opacities=params["opacities"],
+                                          scales=params["scales"], rotations=params["rotations"],
+                                          cov3D_precomp=None)
+        image.backward(G)
+        if reducer is not None:
+            reducer.all_reduce_grads()
+        return radii
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof.enable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        radii = step()
+    fence()
+    dt = time.perf_counter() - t0
+    stage_ms = prof.disable_and_collect()   # mean ms per launch, per stage, over the timed region
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * W * H / (dt / args.steps) / 1e6
+
+    if rank == 0:
+        # workload statistics for the byte model
+        with torch.no_grad():
+            st = impl.preprocess_and_bin(settings, *[params[k].detach() for k in
+                                                     ("means3D", "opacities", "scales", "rotations")],
+                                         None, params["shs"].detach(), None)
+            V = int((st.radii > 0).sum().item())
+            D = st.num_pairs
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        passes = (32 + max(1, (tiles - 1).bit_length()) + 7) // 8
+        b = bytes_v1(N, V, D, W * H, K, tiles, passes)
+        stage_of = {"render_bwd": "render_bwd", "render_fwd": "render_fwd", "preprocess_fwd": "preprocess_fwd",
+                    "preprocess_bwd": "preprocess_bwd", "sort_pairs": "radix_sort",
+                    "duplicate_with_keys": "duplicate_with_keys", "scan_tiles": "scan",
+                    "identify_tile_ranges": "identify_ranges"}
+        dominant = max(stage_ms, key=stage_ms.get)
+        dom_bytes = b[stage_of[dominant]]
+        achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4)}
+        frame_bytes = sum(b.values())
+        out = {
+            "metric": "Mpix/s fwd+bwd @3M Gaussians SH3", "value": round(value, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.config, "gaussians": N, "sh_coeffs": K, "width": W, "height": H,
+                       "drawn": V, "tile_pairs": D, "t_eps": t_eps,
+                       "views_per_step": world, "parallelism": f"views{world}" if world > 1 else "single"},
+            "roofline": roofline,
+            "frame_hbm": {"algorithmic_bytes_v1": frame_bytes,
+                          "frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 4)},
+            "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene):
+    """The CPU oracle (a C port of the reference algorithm) on the same frame, host cores of this box."""
+    from oracle import oracle
+    oracle.build()
+    cores = min(oracle.max_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")))
+    oracle.set_threads(cores)
+    a = lambda t: t.numpy()  # noqa: E731
+    t0 = time.perf_counter()
+    oracle.forward_backward(scene.H, scene.W, scene.sh_degree, a(scene.viewmatrix), a(scene.projmatrix),
+                            a(scene.campos), a(scene.bg), a(scene.means3D), a(scene.opacities),
+                            scales=a(scene.scales), rotations=a(scene.rotations), shs=a(scene.shs),
+                            G_C=a(scene.G))
+    dt = time.perf_counter() - t0
+    return {"value": round(scene.W * scene.H / dt / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"one full frame of the same workload ({scene.means3D.shape[0]} Gaussians, "
+                      f"{scene.W}x{scene.H}, fwd+bwd), {dt:.2f} s wall",
+            "reference_python_loop": "19.48 s for 10k Gaussians 200x200 (0.00205 Mpix/s, BASELINE.md, 8 cores)"}
+
+
+if __name__ == "__main__":
+    main()

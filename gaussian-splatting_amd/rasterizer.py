@@ -25,6 +25,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from .profiling import stage as _stage
 
 TILE = 16
 GRAD_ROW = 16
@@ -68,7 +69,12 @@ class BinningState(NamedTuple):
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    p = t.data_ptr()
+    if p == 0 and t.untyped_storage().nbytes() > 0:   # zero-row view of a real allocation (N == 0)
+        p = t.untyped_storage().data_ptr()
+    return C.c_void_p(p)
 
 
 def _prep(t: Optional[torch.Tensor], name: str, shape_tail, device) -> Optional[torch.Tensor]:
@@ -114,16 +120,18 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
     radii = torch.empty((N,), **i32)
     tiles_touched = torch.empty((N,), **i32)
-    _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
-                                     _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                     _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
-                                     _ptr(radii), _ptr(tiles_touched), st), "gs_preprocess_fwd")
+    with _stage("preprocess_fwd"):
+        _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
+                                         _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                         _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
+                                         _ptr(radii), _ptr(tiles_touched), st), "gs_preprocess_fwd")
     offsets = torch.empty((N,), **i32)
     total = torch.empty((1,), **i32)
     scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
     host_total = C.c_uint32(0)
-    _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(offsets), _ptr(total), _ptr(scan_ws),
-                                 C.byref(host_total), st), "gs_scan_tiles")
+    with _stage("scan_tiles"):
+        _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(offsets), _ptr(total), _ptr(scan_ws),
+                                     C.byref(host_total), st), "gs_scan_tiles")
     D = int(host_total.value)
     tiles_x, tiles_y = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     ntiles = tiles_x * tiles_y
@@ -131,17 +139,20 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     keys_b = torch.empty((max(D, 1),), dtype=torch.int64, device=dev)
     vals_a = torch.empty((max(D, 1),), **i32)
     vals_b = torch.empty((max(D, 1),), **i32)
-    _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(offsets), _ptr(tiles_touched),
-                                          _ptr(keys_a), _ptr(vals_a), st), "gs_duplicate_with_keys")
+    with _stage("duplicate_with_keys"):
+        _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(offsets), _ptr(tiles_touched),
+                                              _ptr(keys_a), _ptr(vals_a), st), "gs_duplicate_with_keys")
     bits = 32 + max(1, (ntiles - 1).bit_length())
     ws_bytes = lib.gs_sort_workspace_bytes(D)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
     in_b = C.c_int(0)
-    _lib.check(lib.gs_sort_pairs(D, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
-                                 _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
+    with _stage("sort_pairs"):
+        _lib.check(lib.gs_sort_pairs(D, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+                                     _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     keys, point_list = (keys_b, vals_b) if in_b.value else (keys_a, vals_a)
     ranges = torch.empty((ntiles, 2), **i32)
-    _lib.check(lib.gs_identify_tile_ranges(D, ntiles, _ptr(keys), _ptr(ranges), st), "gs_identify_tile_ranges")
+    with _stage("identify_tile_ranges"):
+        _lib.check(lib.gs_identify_tile_ranges(D, ntiles, _ptr(keys), _ptr(ranges), st), "gs_identify_tile_ranges")
     return BinningState(splat, radii, tiles_touched, offsets, D, keys[:D], point_list[:D], ranges)
 
 
@@ -162,9 +173,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             aux = torch.empty((3, H, W), dtype=torch.float32, device=dev) if need_grad else None
-            _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(state.splat), _ptr(state.ranges),
-                                         _ptr(state.point_list), _ptr(image), _ptr(depth), _ptr(alpha),
-                                         _ptr(aux), float(t_eps), _stream()), "gs_render_fwd")
+            with _stage("render_fwd"):
+                _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(state.splat), _ptr(state.ranges),
+                                             _ptr(state.point_list), _ptr(image), _ptr(depth), _ptr(alpha),
+                                             _ptr(aux), float(t_eps), _stream()), "gs_render_fwd")
         ctx.settings = settings
         ctx.t_eps = float(t_eps)
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
@@ -213,9 +225,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_depth = gin(g_depth, (1, H, W))
             g_alpha = gin(g_alpha, (1, H, W))
             rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
-            _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux),
-                                         _ptr(depth), _ptr(alpha), _ptr(g_image), _ptr(g_depth),
-                                         _ptr(g_alpha), _ptr(rows), ctx.t_eps, st), "gs_render_bwd")
+            with _stage("render_bwd"):
+                _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux),
+                                             _ptr(depth), _ptr(alpha), _ptr(g_image), _ptr(g_depth),
+                                             _ptr(g_alpha), _ptr(rows), ctx.t_eps, st), "gs_render_bwd")
             needs = ctx.needs_input_grad
             f32 = dict(dtype=torch.float32, device=dev)
             g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
@@ -226,12 +239,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
             g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
             g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
-            _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
-                                             _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                             _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
-                                             _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
-                                             _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors), st),
-                       "gs_preprocess_bwd")
+            with _stage("preprocess_bwd"):
+                _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
+                                                 _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                                 _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
+                                                 _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
+                                                 _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors), st),
+                           "gs_preprocess_bwd")
         if needs[1] and g_means2D is None and ctx.means2D_shape is not None:
             g_means2D = torch.zeros(ctx.means2D_shape, **f32)
         return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov, None, None

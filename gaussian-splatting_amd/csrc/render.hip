@@ -10,22 +10,41 @@
 // with Total = g_C.(C - bg) + g_Z Z + g_A A taken from the forward's outputs.
 //
 // Structure (MI355X): one 256-lane workgroup per 16x16 tile; each of its 4 wave64s owns one 8x8
-// sub-tile (lane = pixel).  A batch of up to 256 splat records is staged in LDS; each wave then
-// ballots the records' boxes against its own sub-tile and walks only the compacted hits, so
-// lanes are not spent on Gaussians whose box misses the whole wave.  A lane stops once its
-// transmittance 1 - A drops below t_eps, a wave when all its lanes stopped (ballot), a
-// workgroup when all its waves did.  t_eps = 0 reproduces the reference exactly (no stop).
+// sub-tile (lane = pixel).  Per batch of the tile's sorted list the workgroup stages (id, box) of
+// every pair in LDS; each wave ballots the boxes against its own sub-tile and keeps only the
+// compacted hits, so lanes are not spent on Gaussians whose box misses the whole wave.  Inside
+// the per-Gaussian loop the 48-byte record is read from LDS with exactly three broadcast
+// ds_read_b128 (12 LDS cycles); the hit index comes from a register via v_readlane.  (The first
+// version used b96/b32/u8 reads, 26 LDS cycles per Gaussian, plus LDS float atomics in the
+// backward: rocprof showed the LDS array 70-80 % busy, profiles/r1a_*.  Scalar s_load of the
+// records was tried and is slower: the scalar cache cannot stream misses.)  A lane stops once its
+// transmittance 1 - A drops below t_eps, a wave when all its lanes stopped (ballot), a workgroup
+// when all its waves did.  t_eps = 0 reproduces the reference exactly (no stop).
 //
-// Backward gradient accumulation: per Gaussian 10 partial sums are reduced over the wave with
-// DPP row shifts / broadcasts (no LDS traffic), added by one lane into LDS accumulators shared
-// by the 4 waves, and flushed once per (tile, Gaussian) as one 40-byte row-shaped float atomic
-// into the 64-byte gradient row of that Gaussian.
+// Backward gradient accumulation: per Gaussian 10 partial sums are reduced over the wave with DPP
+// row shifts + row broadcasts (registers only); lane 63 stores the row into the wave's own LDS
+// slot (plain stores, no LDS atomics); after the batch the 4 waves' rows are summed and flushed
+// once per (tile, Gaussian) as one 40-byte row-shaped float atomic into that Gaussian's 64-byte
+// gradient row.
 //
-// Bound: VALU (exp + ~25 fp32 ops per lane-visit forward, ~70 backward); HBM traffic is the
-// 48-byte record gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
+// Bound: VALU (exp + ~25 fp32 ops per lane-visit forward, ~100 backward); HBM traffic is the
+// record gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
 #include "gsplat_common.h"
 
 namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Rec { f4 q0, q1, q2; };
+
+// j is wave-uniform (v_readlane result): three broadcast ds_read_b128
+__device__ __forceinline__ Rec load_rec(const f4* sq, int j) {
+    Rec r;
+    r.q0 = sq[3 * j];
+    r.q1 = sq[3 * j + 1];
+    r.q2 = sq[3 * j + 2];
+    return r;
+}
 
 struct TileCtx {
     int px, py;        // this lane's pixel
@@ -52,36 +71,41 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
     return c;
 }
 
-// Stage `n` records of the tile's sorted list into LDS, then compact, per wave, the indices of
-// the records whose box overlaps the wave's 8x8 sub-tile.  Returns the wave's hit count.
-__device__ __forceinline__ int stage_and_cull(const float4* __restrict__ splat,
-                                              const uint32_t* __restrict__ point_list, uint32_t base, int n,
-                                              const TileCtx& c, float4* sq0, float4* sq1, float4* sq2,
-                                              uint32_t* sid, uint8_t* widx) {
+// Stage the records of `n` pairs of the tile's sorted list into LDS (sq, 3 x 16 B per pair), then
+// compact, per wave, the batch indices of the pairs whose box overlaps the wave's 8x8 sub-tile into
+// wl[] (in list order).  When posmap is given, posmap[j] = position of pair j in the wave's
+// compacted list, 0xFFFF if culled, and sid[j] = Gaussian id.  Returns the wave's hit count.
+template <int BATCH>
+__device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
+                                              uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
+                                              uint32_t* wl, uint16_t* posmap) {
     const int tid = threadIdx.x;
-    if (tid < n) {
+    if (tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];
-        const float4* p = splat + 3 * (size_t)id;
-        sq0[tid] = p[0];
-        sq1[tid] = p[1];
-        sq2[tid] = p[2];
+        const f4* p = splat + 3 * (size_t)id;
+        sq[3 * tid] = p[0];
+        sq[3 * tid + 1] = p[1];
+        sq[3 * tid + 2] = p[2];
         if (sid) sid[tid] = id;
     }
     __syncthreads();
     const int lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t* squ = (const uint32_t*)sq;
     int count = 0;
 #pragma unroll
-    for (int r = 0; r < GS_BLOCK / 64; ++r) {
+    for (int r = 0; r < BATCH / 64; ++r) {
         const int j = r * 64 + lane;
         bool hit = false;
         if (j < n) {
-            const uint32_t rx = __float_as_uint(sq1[j].w), ry = __float_as_uint(sq2[j].w);
+            const uint32_t rx = squ[12 * j + 7], ry = squ[12 * j + 11];
             const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
             hit = xmin < c.sx0 + GS_SUB && xmax > c.sx0 && ymin < c.sy0 + GS_SUB && ymax > c.sy0;
         }
         const uint64_t m = __ballot(hit);
-        if (hit) widx[count + __popcll(m & lt)] = (uint8_t)j;
+        const int pos = count + __popcll(m & lt);
+        if (hit) wl[pos] = (uint32_t)j;
+        if (posmap) posmap[j] = hit ? (uint16_t)pos : (uint16_t)0xFFFF;
         count += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -94,36 +118,42 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     int H, int W, int tiles_x, int ntiles, const float* __restrict__ bg, const float4* __restrict__ splat,
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, float* __restrict__ out_img,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ aux_rgb, float t_eps) {
-    __shared__ float4 sq0[GS_BLOCK], sq1[GS_BLOCK], sq2[GS_BLOCK];
-    __shared__ uint8_t widx_all[GS_BLOCK / 64][GS_BLOCK];
+    constexpr int BATCH = 256;
+    __shared__ f4 sq[3 * BATCH];
+    __shared__ uint32_t wl_all[GS_BLOCK / 64][BATCH];
     const int tile = tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
-    uint8_t* widx = widx_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    uint32_t* wl = wl_all[threadIdx.x >> 6];
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
     float A = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Z = 0.f;
     bool done = !c.inside;
-    for (uint32_t base = range.x; base < range.y; base += GS_BLOCK) {
+    for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(done)) break;
-        const int n = min((int)(range.y - base), GS_BLOCK);
-        const int count = stage_and_cull(splat, point_list, base, n, c, sq0, sq1, sq2, nullptr, widx);
-        for (int k = 0; k < count; ++k) {
-            if ((k & 7) == 0 && __all(done)) break;
-            const int j = widx[k];
-            const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
-            const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
-            const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
-            const bool act = !done && c.px >= xmin && c.px < xmax && c.py >= ymin && c.py < ymax;
-            const float dx = fpx - q0.x, dy = fpy - q0.y;
-            const float power = -0.5f * ((q0.z * dx * dx + (q0.w + q0.w) * dx * dy) + q1.x * dy * dy);
-            const float w = __expf(power) * q1.y;
-            const float alpha = act ? w * (1.0f - A) : 0.0f;
-            Cr += alpha * q2.x;
-            Cg += alpha * q2.y;
-            Cb += alpha * q2.z;
-            Z += alpha * q1.z;
-            A += alpha;
-            done = done || (1.0f - A) < t_eps;
+        const int n = min((int)(range.y - base), BATCH);
+        const int count = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr);
+        bool stop = false;
+        for (int c0 = 0; c0 < count && !stop; c0 += 64) {
+            const int cn = min(64, count - c0);
+            const uint32_t jv = wl[c0 + lane];
+            for (int kk = 0; kk < cn; ++kk) {
+                if ((kk & 7) == 0 && __all(done)) { stop = true; break; }
+                const Rec rec = load_rec(sq, __builtin_amdgcn_readlane(jv, kk));
+                const uint32_t rx = __float_as_uint(rec.q1.w), ry = __float_as_uint(rec.q2.w);
+                const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
+                const bool act = !done && c.px >= xmin && c.px < xmax && c.py >= ymin && c.py < ymax;
+                const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
+                const float power = -0.5f * ((rec.q0.z * dx * dx + (rec.q0.w + rec.q0.w) * dx * dy) + rec.q1.x * dy * dy);
+                const float w = __expf(power) * rec.q1.y;
+                const float alpha = act ? w * (1.0f - A) : 0.0f;
+                Cr += alpha * rec.q2.x;
+                Cg += alpha * rec.q2.y;
+                Cb += alpha * rec.q2.z;
+                Z += alpha * rec.q1.z;
+                A += alpha;
+                done = done || (1.0f - A) < t_eps;
+            }
         }
     }
     if (c.inside) {
@@ -141,18 +171,45 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     }
 }
 
-// sum over the 64 lanes; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#define GS_DPP_ADD(ctrl, rmask)                                                                          \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, true))
-    GS_DPP_ADD(0x111, 0xF);  // row_shr:1
-    GS_DPP_ADD(0x112, 0xF);  // row_shr:2
-    GS_DPP_ADD(0x114, 0xF);  // row_shr:4
-    GS_DPP_ADD(0x118, 0xF);  // row_shr:8   -> lane 15 of each row holds the row sum
-    GS_DPP_ADD(0x142, 0xA);  // row_bcast:15 into rows 1 and 3
-    GS_DPP_ADD(0x143, 0xC);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+// Sum each of the 10 values over the 64 lanes; totals are valid in lane 63.
+__device__ __forceinline__ void wave_sum10_to_lane63(float (&v)[10]) {
+#define GS_DPP_ADD(x, ctrl) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, true))
+#pragma unroll
+    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x111);  // row_shr:1
+#pragma unroll
+    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x112);  // row_shr:2
+#pragma unroll
+    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x114);  // row_shr:4
+#pragma unroll
+    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x118);  // row_shr:8 -> lane 15 of each row = row total
 #undef GS_DPP_ADD
-    return v;
+    // row_bcast:15 into rows 1,3 then row_bcast:31 into rows 2,3 (hipcc does not fuse these from the
+    // builtin; the leading s_nop covers the VALU-write -> DPP-read hazard, later reads are >= 9 apart)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %9, %9 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]));
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
@@ -161,15 +218,17 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
     const float* __restrict__ g_depth, const float* __restrict__ g_alpha, float* __restrict__ grad_rows,
     float t_eps) {
-    __shared__ float4 sq0[GS_BLOCK], sq1[GS_BLOCK], sq2[GS_BLOCK];
-    __shared__ uint32_t sid[GS_BLOCK];
-    __shared__ uint8_t widx_all[GS_BLOCK / 64][GS_BLOCK];
-    __shared__ float acc[GS_BLOCK][10];
-    __shared__ uint32_t hit[GS_BLOCK];
+    constexpr int BATCH = 128;
+    constexpr int NW = GS_BLOCK / 64;
+    __shared__ f4 sq[3 * BATCH];
+    __shared__ uint32_t sid[BATCH];
+    __shared__ uint32_t wl_all[NW][BATCH];
+    __shared__ uint16_t posmap_all[NW][BATCH];
+    __shared__ f4 acc_all[NW][BATCH][3];   // per wave, per compacted hit: 10 sums, [10] = "written" flag
     const int tile = tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
-    const int tid = threadIdx.x, lane = tid & 63;
-    uint8_t* widx = widx_all[tid >> 6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* wl = wl_all[wave];
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
     float gr = 0.f, gg = 0.f, gb = 0.f, gz = 0.f, ga = 0.f, total = 0.f;
@@ -185,80 +244,80 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     }
     float A = 0.f, prefix = 0.f;
     bool done = !c.inside;
-    for (uint32_t base = range.x; base < range.y; base += GS_BLOCK) {
+    for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(done)) break;
-        const int n = min((int)(range.y - base), GS_BLOCK);
+        const int n = min((int)(range.y - base), BATCH);
+        // clear the "written" flags of every slot (2 per lane: NW*BATCH = 512 slots)
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc[tid][k] = 0.0f;
-        hit[tid] = 0;
-        const int count = stage_and_cull(splat, point_list, base, n, c, sq0, sq1, sq2, sid, widx);
-        for (int k = 0; k < count; ++k) {
-            if ((k & 7) == 0 && __all(done)) break;
-            const int j = widx[k];
-            const float4 q0 = sq0[j], q1 = sq1[j], q2 = sq2[j];
-            const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
-            const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
-            const bool act = !done && c.px >= xmin && c.px < xmax && c.py >= ymin && c.py < ymax;
-            if (!__any(act)) continue;
-            const float ca = q0.z, cb = q0.w, cd = q1.x, op = q1.y, z = q1.z;
-            const float dx = fpx - q0.x, dy = fpy - q0.y;
-            const float power = -0.5f * ((ca * dx * dx + (cb + cb) * dx * dy) + cd * dy * dy);
-            const float G = act ? __expf(power) : 0.0f;  // inactive lanes must not leak inf/NaN into the sums
-            const float w = G * op;
-            const float T = 1.0f - A;
-            const float alpha = act ? w * T : 0.0f;
-            const float u = (q2.x * gr + q2.y * gg + q2.z * gb) + z * gz + ga;
-            prefix += u * alpha;
-            const float suffix = total - prefix;
-            const float inv = __frcp_rn(fmaxf(1.0f - w, 1e-6f));
-            const float dLdw = act ? (T * u - suffix * inv) : 0.0f;
-            const float dLdp = w * dLdw;
-            float v0 = dLdp * (ca * dx + cb * dy);
-            float v1 = dLdp * (cd * dy + cb * dx);
-            const float h = -0.5f * dLdp;
-            float v2 = h * dx * dx;
-            float v3 = h * dx * dy;
-            float v4 = h * dy * dy;
-            float v5 = G * dLdw;
-            float v6 = alpha * gr;
-            float v7 = alpha * gg;
-            float v8 = alpha * gb;
-            float v9 = alpha * gz;
-            A += alpha;
-            done = done || (1.0f - A) < t_eps;
-            v0 = wave_sum_to_lane63(v0);
-            v1 = wave_sum_to_lane63(v1);
-            v2 = wave_sum_to_lane63(v2);
-            v3 = wave_sum_to_lane63(v3);
-            v4 = wave_sum_to_lane63(v4);
-            v5 = wave_sum_to_lane63(v5);
-            v6 = wave_sum_to_lane63(v6);
-            v7 = wave_sum_to_lane63(v7);
-            v8 = wave_sum_to_lane63(v8);
-            v9 = wave_sum_to_lane63(v9);
-            if (lane == 63) {
-                float* a = acc[j];
-                atomicAdd(a + 0, v0);
-                atomicAdd(a + 1, v1);
-                atomicAdd(a + 2, v2);
-                atomicAdd(a + 3, v3);
-                atomicAdd(a + 4, v4);
-                atomicAdd(a + 5, v5);
-                atomicAdd(a + 6, v6);
-                atomicAdd(a + 7, v7);
-                atomicAdd(a + 8, v8);
-                atomicAdd(a + 9, v9);
-                hit[j] = 1;
+        for (int s = tid; s < NW * BATCH; s += GS_BLOCK) ((float*)&acc_all[0][0][0])[s * 12 + 10] = 0.0f;
+        const int count = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl,
+                                                posmap_all[wave]);
+        bool stop = false;
+        for (int c0 = 0; c0 < count && !stop; c0 += 64) {
+            const int cn = min(64, count - c0);
+            const uint32_t jv = wl[c0 + lane];
+            for (int kk = 0; kk < cn; ++kk) {
+                if ((kk & 7) == 0 && __all(done)) { stop = true; break; }
+                const Rec rec = load_rec(sq, __builtin_amdgcn_readlane(jv, kk));
+                const uint32_t rx = __float_as_uint(rec.q1.w), ry = __float_as_uint(rec.q2.w);
+                const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
+                const bool act = !done && c.px >= xmin && c.px < xmax && c.py >= ymin && c.py < ymax;
+                if (!__any(act)) continue;   // slot keeps flag 0
+                const float ca = rec.q0.z, cb = rec.q0.w, cd = rec.q1.x, op = rec.q1.y, z = rec.q1.z;
+                const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
+                const float power = -0.5f * ((ca * dx * dx + (cb + cb) * dx * dy) + cd * dy * dy);
+                const float G = act ? __expf(power) : 0.0f;  // inactive lanes must not leak inf/NaN into the sums
+                const float w = G * op;
+                const float T = 1.0f - A;
+                const float alpha = w * T;
+                const float u = (rec.q2.x * gr + rec.q2.y * gg + rec.q2.z * gb) + z * gz + ga;
+                prefix += u * alpha;
+                const float suffix = total - prefix;
+                const float inv = __builtin_amdgcn_rcpf(fmaxf(1.0f - w, 1e-6f));
+                const float dLdw = act ? (T * u - suffix * inv) : 0.0f;
+                const float dLdp = w * dLdw;
+                const float h = -0.5f * dLdp;
+                float v[10];
+                v[0] = dLdp * (ca * dx + cb * dy);
+                v[1] = dLdp * (cd * dy + cb * dx);
+                v[2] = h * dx * dx;
+                v[3] = h * dx * dy;
+                v[4] = h * dy * dy;
+                v[5] = G * dLdw;
+                v[6] = alpha * gr;
+                v[7] = alpha * gg;
+                v[8] = alpha * gb;
+                v[9] = alpha * gz;
+                A += alpha;
+                done = done || (1.0f - A) < t_eps;
+                wave_sum10_to_lane63(v);
+                if (lane == 63) {
+                    f4* a = acc_all[wave][c0 + kk];
+                    a[0] = (f4){v[0], v[1], v[2], v[3]};
+                    a[1] = (f4){v[4], v[5], v[6], v[7]};
+                    a[2] = (f4){v[8], v[9], 1.0f, 0.0f};
+                }
             }
         }
         __syncthreads();
-        // flush: 16 lanes per Gaussian, lanes 0..9 carry the row -> row-shaped float atomics
+        // flush: 16 lanes per pair, lanes 0..9 carry the row summed over the waves that hit it
         const int sub = tid & 15;
-#pragma unroll 4
-        for (int r = 0; r < GS_BLOCK / 16; ++r) {
-            const int gidx = r * 16 + (tid >> 4);
-            if (gidx < n && sub < 10 && hit[gidx])
-                atomicAdd(grad_rows + (size_t)sid[gidx] * GS_GRAD_ROW + sub, acc[gidx][sub]);
+#pragma unroll 2
+        for (int r = 0; r < BATCH / 16; ++r) {
+            const int j = r * 16 + (tid >> 4);
+            if (j < n && sub < 10) {
+                float sum = 0.0f;
+                bool any = false;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {
+                    const uint32_t p = posmap_all[w2][j];
+                    if (p != 0xFFFFu) {
+                        const float* a = (const float*)&acc_all[w2][p][0];
+                        if (a[10] != 0.0f) { sum += a[sub]; any = true; }
+                    }
+                }
+                if (any) atomicAdd(grad_rows + (size_t)sid[j] * GS_GRAD_ROW + sub, sum);
+            }
         }
     }
 }

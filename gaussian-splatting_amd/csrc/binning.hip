@@ -12,7 +12,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int tiles_x,
+__global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int tiles_x, int row_b, int row_e,
                                                                    const float4* __restrict__ splat,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ tiles_touched,
@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int til
     const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
     const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
     const int tx0 = xmin / GS_TILE, tx1 = (xmax - 1) / GS_TILE + 1;
-    const int ty0 = ymin / GS_TILE, ty1 = (ymax - 1) / GS_TILE + 1;
+    int ty0 = ymin / GS_TILE, ty1 = (ymax - 1) / GS_TILE + 1;
+    ty0 = ty0 > row_b ? ty0 : row_b;
+    ty1 = ty1 < row_e ? ty1 : row_e;
     const uint32_t dk = gs_depth_key_desc(q1.z);
     size_t o = offsets[i];
     for (int ty = ty0; ty < ty1; ++ty)
@@ -50,13 +52,13 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, 
 
 extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* offsets,
                                       const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
-                                      void* stream_) {
+                                      int tile_row_begin, int tile_row_end, void* stream_) {
     GS_REQUIRE(N >= 0 && W > 0, "bad arguments");
     if (N == 0) return GS_OK;
     GS_REQUIRE(splat && offsets && tiles_touched && keys && vals, "null buffer");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream_, N,
-                       tiles_x, (const float4*)splat, offsets, tiles_touched, keys, vals);
+                       tiles_x, tile_row_begin, tile_row_end, (const float4*)splat, offsets, tiles_touched, keys, vals);
     GS_CHECK_LAUNCH("duplicate_with_keys");
     return GS_OK;
 }

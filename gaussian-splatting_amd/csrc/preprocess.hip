@@ -48,7 +48,7 @@ struct Geom {
 };
 
 // All of this must round exactly like oracle/gs_oracle.c::gso_preprocess.
-__device__ __forceinline__ void project_gaussian(int i, int H, int W, const float* __restrict__ view,
+__device__ __forceinline__ void project_gaussian(int i, int H, int W, int row_b, int row_e, const float* __restrict__ view,
                                                  const float* __restrict__ proj,
                                                  const float* __restrict__ means3D,
                                                  const float* __restrict__ scales,
@@ -141,8 +141,10 @@ __device__ __forceinline__ void project_gaussian(int i, int H, int W, const floa
         const float m = (sx > sy) ? sx : sy;
         g.radius = (m >= 1.0f && m < 32767.0f) ? (int)ceilf(m) : (m >= 32767.0f ? 32767 : 1);
         const int tx0 = g.xmin / GS_TILE, tx1 = (g.xmax - 1) / GS_TILE + 1;
-        const int ty0 = g.ymin / GS_TILE, ty1 = (g.ymax - 1) / GS_TILE + 1;
-        g.tiles = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
+        int ty0 = g.ymin / GS_TILE, ty1 = (g.ymax - 1) / GS_TILE + 1;
+        ty0 = ty0 > row_b ? ty0 : row_b;      // band of tile rows owned by this call (whole frame: 0..tiles_y)
+        ty1 = ty1 < row_e ? ty1 : row_e;
+        g.tiles = ty1 > ty0 ? (uint32_t)((tx1 - tx0) * (ty1 - ty0)) : 0u;
     }
 }
 
@@ -227,7 +229,7 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int i, in
 
 template <int DEG, bool VEC4>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
-    int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
+    int N, int K, int H, int W, int row_b, int row_e, const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ cov6, const float* __restrict__ opacities,
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     Geom g;
-    project_gaussian(i, H, W, view, proj, means3D, scales, rots, cov6, g);
+    project_gaussian(i, H, W, row_b, row_e, view, proj, means3D, scales, rots, cov6, g);
     radii[i] = g.radius;
     tiles_touched[i] = g.tiles;
     if (!g.drawn) return;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int sh_written = 0;
     if (drawn) {
         Geom g;
-        project_gaussian(i, H, W, view, proj, means3D, scales, rots, cov6, g);
+        project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
         const float4 r0 = grad_rows[4 * (size_t)i], r1 = grad_rows[4 * (size_t)i + 1],
                      r2 = grad_rows[4 * (size_t)i + 2];
         const float d_mx = r0.x, d_my = r0.y, d_a = r0.z, d_b = r0.w;
@@ -462,16 +464,16 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 }
 
 template <int DEG>
-int launch_fwd(bool vec4, int N, int K, int H, int W, const float* view, const float* proj,
+int launch_fwd(bool vec4, int N, int K, int H, int W, int row_b, int row_e, const float* view, const float* proj,
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* opac, const float* shs, const float* colors,
                float4* splat, int32_t* radii, uint32_t* tiles, hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
     if (vec4)
-        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, view, proj,
+        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
                            campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles);
     else
-        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, view, proj,
+        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
                            campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles);
     GS_CHECK_LAUNCH("preprocess_fwd");
     return GS_OK;
@@ -516,23 +518,25 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
                                  const float* projmatrix, const float* campos, const float* means3D,
                                  const float* scales, const float* rotations, const float* cov3D_precomp,
                                  const float* opacities, const float* shs, const float* colors_precomp,
-                                 void* splat, int32_t* radii, uint32_t* tiles_touched, void* stream_) {
+                                 void* splat, int32_t* radii, uint32_t* tiles_touched, int tile_row_begin,
+                                 int tile_row_end, void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
     GS_REQUIRE(viewmatrix && projmatrix && campos && opacities && splat && radii && tiles_touched, "null argument");
     GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
     GS_REQUIRE(((uintptr_t)splat & 15) == 0, "splat buffer must be 16-byte aligned");
+    GS_REQUIRE(tile_row_begin >= 0 && tile_row_end >= tile_row_begin, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0);
     const int deg = shs ? sh_degree : 0;
     float4* sp = (float4*)splat;
     switch (deg) {
-        case 0: return launch_fwd<0>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
-        case 1: return launch_fwd<1>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
-        case 2: return launch_fwd<2>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
-        default: return launch_fwd<3>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
     }
 }
 

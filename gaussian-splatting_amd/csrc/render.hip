@@ -115,13 +115,13 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
 
 template <bool AUX>
 __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
-    int H, int W, int tiles_x, int ntiles, const float* __restrict__ bg, const float4* __restrict__ splat,
+    int H, int W, int tiles_x, int tile0, int ntiles, const float* __restrict__ bg, const float4* __restrict__ splat,
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, float* __restrict__ out_img,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ aux_rgb, float t_eps) {
     constexpr int BATCH = 256;
     __shared__ f4 sq[3 * BATCH];
     __shared__ uint32_t wl_all[GS_BLOCK / 64][BATCH];
-    const int tile = tile_of_block(blockIdx.x, ntiles);
+    const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int lane = threadIdx.x & 63;
     uint32_t* wl = wl_all[threadIdx.x >> 6];
@@ -213,7 +213,7 @@ __device__ __forceinline__ void wave_sum10_to_lane63(float (&v)[10]) {
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
-    int H, int W, int tiles_x, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
+    int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
     const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
     const float* __restrict__ g_depth, const float* __restrict__ g_alpha, float* __restrict__ grad_rows,
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     __shared__ uint32_t wl_all[NW][BATCH];
     __shared__ uint16_t posmap_all[NW][BATCH];
     __shared__ f4 acc_all[NW][BATCH][3];   // per wave, per compacted hit: 10 sums, [10] = "written" flag
-    const int tile = tile_of_block(blockIdx.x, ntiles);
+    const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* wl = wl_all[wave];
@@ -326,19 +326,22 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
 
 extern "C" int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32_t* ranges,
                              const uint32_t* point_list, float* out_image, float* out_depth, float* out_alpha,
-                             float* aux_rgb, float t_eps, void* stream_) {
+                             float* aux_rgb, float t_eps, int tile_row_begin, int tile_row_end, void* stream_) {
     GS_REQUIRE(H > 0 && W > 0 && H < 65536 && W < 65536, "image size %dx%d outside 1..65535", W, H);
     GS_REQUIRE(bg && splat && ranges && out_image && out_depth && out_alpha, "null argument");
     GS_REQUIRE(t_eps >= 0.0f && t_eps < 1.0f, "t_eps must be in [0,1)");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
-    const int ntiles = tiles_x * tiles_y;
+    GS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
+    if (tile_row_end > tiles_y) tile_row_end = tiles_y;
+    if (tile_row_begin >= tile_row_end) return GS_OK;
+    const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
     hipStream_t stream = (hipStream_t)stream_;
     if (aux_rgb)
-        hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(ntiles), dim3(GS_BLOCK), 0, stream, H, W, tiles_x, ntiles,
+        hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(ntiles), dim3(GS_BLOCK), 0, stream, H, W, tiles_x, tile0, ntiles,
                            bg, (const float4*)splat, (const uint2*)ranges, point_list, out_image, out_depth,
                            out_alpha, aux_rgb, t_eps);
     else
-        hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(ntiles), dim3(GS_BLOCK), 0, stream, H, W, tiles_x, ntiles,
+        hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(ntiles), dim3(GS_BLOCK), 0, stream, H, W, tiles_x, tile0, ntiles,
                            bg, (const float4*)splat, (const uint2*)ranges, point_list, out_image, out_depth,
                            out_alpha, aux_rgb, t_eps);
     GS_CHECK_LAUNCH("render_fwd");
@@ -349,13 +352,17 @@ extern "C" int gs_render_fwd(int H, int W, const float* bg, const void* splat, c
 extern "C" int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges,
                              const uint32_t* point_list, const float* aux_rgb, const float* out_depth,
                              const float* out_alpha, const float* g_image, const float* g_depth,
-                             const float* g_alpha, float* grad_rows, float t_eps, void* stream_) {
+                             const float* g_alpha, float* grad_rows, float t_eps, int tile_row_begin,
+                             int tile_row_end, void* stream_) {
     GS_REQUIRE(H > 0 && W > 0 && H < 65536 && W < 65536, "image size %dx%d outside 1..65535", W, H);
     GS_REQUIRE(splat && ranges && aux_rgb && out_depth && out_alpha && g_image && grad_rows, "null argument");
     GS_REQUIRE(t_eps >= 0.0f && t_eps < 1.0f, "t_eps must be in [0,1)");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
-    const int ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, ntiles,
+    GS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
+    if (tile_row_end > tiles_y) tile_row_end = tiles_y;
+    if (tile_row_begin >= tile_row_end) return GS_OK;
+    const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
                        (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
                        g_image, g_depth, g_alpha, grad_rows, t_eps);
     GS_CHECK_LAUNCH("render_bwd");

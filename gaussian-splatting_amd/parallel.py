@@ -77,3 +77,48 @@ def reduce_densify_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, 
     dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
+
+def render_band(raster_settings, rank: int, world: int, t_eps=None, **inputs):
+    """This rank's share of a tile-row sharded frame: renders only its band of 16-pixel tile rows.
+
+    Every rank holds all Gaussians; it preprocesses them all but emits / sorts / composites only the
+    (tile, Gaussian) pairs of its own band, so there is no exchange on the data path.  Returns
+    (image_band (3,h,W), depth_band (1,h,W), alpha_band (1,h,W), (y0, y1)); h may be 0.
+    Concatenating the bands of all ranks is bit-identical to the single-GPU frame.
+    """
+    from .rasterizer import DEFAULT_T_EPS, GaussianRasterizer, TILE
+    H = raster_settings.image_height
+    tiles_y = (H + TILE - 1) // TILE
+    b, e = tile_row_band(tiles_y, rank, world)
+    y0, y1 = min(b * TILE, H), min(e * TILE, H)
+    rast = GaussianRasterizer(raster_settings, t_eps=DEFAULT_T_EPS if t_eps is None else t_eps, tile_rows=(b, e))
+    image, radii, depth, alpha = rast(**inputs)
+    return image[:, y0:y1].contiguous(), depth[:, y0:y1].contiguous(), alpha[:, y0:y1].contiguous(), (y0, y1)
+
+
+def gather_bands(band: torch.Tensor, H: int, dst: int = 0, group: Optional[dist.ProcessGroup] = None):
+    """Collect (C,h_r,W) bands (h_r as given by tile_row_band) into the (C,H,W) frame on rank `dst`.
+
+    Bands are padded to the tallest one so one all_gather moves them (RCCL has no ragged gather);
+    returns the frame on `dst`, None elsewhere.  With no process group: returns the band itself.
+    """
+    from .rasterizer import TILE
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return band
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    tiles_y = (H + TILE - 1) // TILE
+    spans = []
+    for r in range(world):
+        b, e = tile_row_band(tiles_y, r, world)
+        spans.append((min(b * TILE, H), min(e * TILE, H)))
+    hmax = max(y1 - y0 for y0, y1 in spans)
+    C, h, W = band.shape
+    assert h == spans[rank][1] - spans[rank][0], "band height does not match this rank's tile rows"
+    padded = band.new_zeros((C, hmax, W))
+    padded[:, :h] = band
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][:, :spans[r][1] - spans[r][0]] for r in range(world)], dim=1)

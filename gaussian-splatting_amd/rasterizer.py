@@ -104,8 +104,18 @@ def _camera_tensor(t, n, name, device):
     return t
 
 
+def _band(settings, tile_rows):
+    tiles_y = (settings.image_height + TILE - 1) // TILE
+    if tile_rows is None:
+        return 0, tiles_y
+    b, e = int(tile_rows[0]), int(tile_rows[1])
+    if not (0 <= b <= e <= tiles_y):
+        raise ValueError(f"tile_rows {tile_rows} outside 0..{tiles_y}")
+    return b, e
+
+
 def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
-                       cov3D_precomp, shs, colors_precomp) -> BinningState:
+                       cov3D_precomp, shs, colors_precomp, tile_rows=None) -> BinningState:
     """preprocess -> scan -> duplicate_with_keys -> radix sort -> tile ranges (all on the current stream)."""
     lib = _lib.load()
     dev = means3D.device
@@ -116,6 +126,7 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
     campos = _camera_tensor(settings.campos, 3, "campos", dev)
     st = _stream()
+    row_b, row_e = _band(settings, tile_rows)
     i32 = dict(dtype=torch.int32, device=dev)
     splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
     radii = torch.empty((N,), **i32)
@@ -124,7 +135,7 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
         _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
-                                         _ptr(radii), _ptr(tiles_touched), st), "gs_preprocess_fwd")
+                                         _ptr(radii), _ptr(tiles_touched), row_b, row_e, st), "gs_preprocess_fwd")
     offsets = torch.empty((N,), **i32)
     total = torch.empty((1,), **i32)
     scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
@@ -141,7 +152,8 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     vals_b = torch.empty((max(D, 1),), **i32)
     with _stage("duplicate_with_keys"):
         _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(offsets), _ptr(tiles_touched),
-                                              _ptr(keys_a), _ptr(vals_a), st), "gs_duplicate_with_keys")
+                                              _ptr(keys_a), _ptr(vals_a), row_b, row_e, st),
+                   "gs_duplicate_with_keys")
     bits = 32 + max(1, (ntiles - 1).bit_length())
     ws_bytes = lib.gs_sort_workspace_bytes(D)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
@@ -159,14 +171,15 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                settings, t_eps):
+                settings, t_eps, tile_rows=None):
         lib = _lib.load()
         dev = means3D.device
         H, W = settings.image_height, settings.image_width
         bg = _camera_tensor(settings.bg, 3, "bg", dev)
         with torch.cuda.device(dev):
+            row_b, row_e = _band(settings, tile_rows)
             state = preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                       colors_precomp)
+                                       colors_precomp, tile_rows)
             need_grad = any(t is not None and t.requires_grad for t in
                             (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
             image = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -176,9 +189,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             with _stage("render_fwd"):
                 _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(state.splat), _ptr(state.ranges),
                                              _ptr(state.point_list), _ptr(image), _ptr(depth), _ptr(alpha),
-                                             _ptr(aux), float(t_eps), _stream()), "gs_render_fwd")
+                                             _ptr(aux), float(t_eps), row_b, row_e, _stream()), "gs_render_fwd")
         ctx.settings = settings
         ctx.t_eps = float(t_eps)
+        ctx.band = (row_b, row_e)
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         saved = [means3D, opacities, state.splat, state.radii, state.point_list, state.ranges, depth, alpha]
@@ -228,7 +242,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             with _stage("render_bwd"):
                 _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux),
                                              _ptr(depth), _ptr(alpha), _ptr(g_image), _ptr(g_depth),
-                                             _ptr(g_alpha), _ptr(rows), ctx.t_eps, st), "gs_render_bwd")
+                                             _ptr(g_alpha), _ptr(rows), ctx.t_eps, ctx.band[0], ctx.band[1], st),
+                           "gs_render_bwd")
             needs = ctx.needs_input_grad
             f32 = dict(dtype=torch.float32, device=dev)
             g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
@@ -248,22 +263,26 @@ class _RasterizeGaussians(torch.autograd.Function):
                            "gs_preprocess_bwd")
         if needs[1] and g_means2D is None and ctx.means2D_shape is not None:
             g_means2D = torch.zeros(ctx.means2D_shape, **f32)
-        return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov, None, None
+        return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                        raster_settings, t_eps: float = DEFAULT_T_EPS):
+                        raster_settings, t_eps: float = DEFAULT_T_EPS, tile_rows=None):
+    """tile_rows = (begin, end): render only that band of 16-pixel tile rows (pixels outside it are
+    left unwritten) -- the unit of work of tile-row sharded inference."""
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                     cov3D_precomp, raster_settings, t_eps)
+                                     cov3D_precomp, raster_settings, t_eps, tile_rows)
 
 
 class GaussianRasterizer(nn.Module):
     """Drop-in for the class the reference constructs at gaussian_renderer/__init__.py:585 and calls at :635."""
 
-    def __init__(self, raster_settings: GaussianRasterizationSettings, t_eps: float = DEFAULT_T_EPS):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, t_eps: float = DEFAULT_T_EPS,
+                 tile_rows=None):
         super().__init__()
         self.raster_settings = raster_settings
         self.t_eps = t_eps
+        self.tile_rows = tile_rows
 
     def forward(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
                 rotations=None, cov3D_precomp=None, cov3Ds_precomp=None):
@@ -281,13 +300,13 @@ class GaussianRasterizer(nn.Module):
             raise ValueError("means3D must be a (N,3) tensor")
         dev = means3D.device
         N = means3D.shape[0]
-        means3D = _prep(means3D, "means3D", (3,), dev)
         if shs is not None:
             if shs.dim() != 3 or shs.shape[2] != 3:
                 raise ValueError(f"shs must be (N,K,3), got {tuple(shs.shape)}")
             if (rs.sh_degree + 1) ** 2 > shs.shape[1]:
                 raise ValueError(f"sh_degree {rs.sh_degree} needs {(rs.sh_degree + 1) ** 2} coefficients, shs has {shs.shape[1]}")
-            shs = _prep(shs, "shs", None, dev)
+        means3D = _prep(means3D, "means3D", (3,), dev)
+        shs = _prep(shs, "shs", None, dev)
         colors_precomp = _prep(colors_precomp, "colors_precomp", (3,), dev)
         opacities = _prep(opacities.reshape(N, 1) if opacities.dim() == 1 else opacities, "opacities", (1,), dev)
         scales = _prep(scales, "scales", (3,), dev)
@@ -300,4 +319,4 @@ class GaussianRasterizer(nn.Module):
         if not (0 <= rs.sh_degree <= 3):
             raise ValueError(f"sh_degree must be 0..3, got {rs.sh_degree}")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, self.t_eps)
+                                   cov3D_precomp, rs, self.t_eps, self.tile_rows)

@@ -1,0 +1,132 @@
+/*
+ * gsplat.h -- C-ABI of libgsplat_hip.so, the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of Ainsley0917/gaussian-splatting:
+ * the slot the reference fills with the third-party `diff_gaussian_rasterization` extension
+ * (reference gaussian_renderer/__init__.py:19-27 import, :549-668 adapter).  The reference is
+ * Python, so the binding a maintainer adds is a ctypes stub (the one shipped here
+ * is gaussian-splatting_amd/_lib.py + rasterizer.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32 / int32 / uint32 / uint64, contiguous) unless named
+ *     host_*; the library never allocates, frees or keeps caller memory; scratch is passed in.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     except gs_scan_tiles when host_total != NULL (one 4-byte read-back of the pair count D).
+ *   - every function returns 0 on success, <0 on error (GS_ERR_*); gs_last_error() gives the
+ *     message of the calling thread's last error.  No function allocates device memory.
+ *   - matrices are row-major 4x4 applied as out[r] = sum_c M[r][c] * (p,1)[c], exactly as the
+ *     reference's built-in rasterizer applies them (gaussian_renderer/__init__.py:122,125).
+ *   - semantics (culling, hard 3-sigma integer boxes, far-to-near compositing with alpha_acc, no
+ *     alpha clamp, background added un-attenuated) are those of the reference's built-in
+ *     PyTorch rasterizer, gaussian_renderer/__init__.py:64-442 (the parity oracle).
+ *
+ * Re-entrancy: no global mutable state except the thread-local error string.
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK 0
+#define GS_ERR_ARG (-1)  /* bad argument (null pointer, size, alignment, missing/duplicate input) */
+#define GS_ERR_HIP (-2)  /* a HIP call or kernel launch failed */
+#define GS_ERR_SIZE (-3) /* size beyond a stated limit */
+
+int gs_version(void);            /* 100 = 0.1.0 */
+const char* gs_last_error(void); /* message of this thread's last failing call */
+int gs_tile_size(void);          /* 16: tile edge used by keys and ranges */
+int gs_grad_row_floats(void);    /* 16: floats per per-Gaussian gradient row (see gs_render_bwd) */
+
+/*
+ * Per-Gaussian forward stage.  Replaces GaussianRasterizer.forward's vectorised prologue
+ * (gaussian_renderer/__init__.py:108-149: compute_colors_from_sh :185, projection :116-133,
+ * compute_cov3D :210 / cov_from_upper_triangular :266, project_cov3D_to_2D :291) and the
+ * per-Gaussian tests at the top of the splat loop (:368-402).
+ * Exactly one of shs (N,K,3) / colors_precomp (N,3); exactly one of (scales (N,3), rotations
+ * (N,4)) / cov3D_precomp (N,6).  rotations and splat must be 16-byte aligned.
+ * [tile_row_begin, tile_row_end) is the band of 16-pixel tile rows this call owns (whole frame:
+ * 0 .. ceil(H/16)); tiles_touched counts only tiles inside the band (tile-row sharded inference,
+ * BASELINE.json config 5); radii are independent of the band.
+ * Outputs: splat (N x 12 floats, 48-byte records, layout in csrc/gsplat_common.h; rows of culled
+ * Gaussians are not written), radii (N) int32 = ceil(3 sigma_max) or 0 when not drawn,
+ * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.
+ */
+int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
+                      const float* projmatrix, const float* campos, const float* means3D,
+                      const float* scales, const float* rotations, const float* cov3D_precomp,
+                      const float* opacities, const float* shs, const float* colors_precomp,
+                      void* splat, int32_t* radii, uint32_t* tiles_touched, int tile_row_begin,
+                      int tile_row_end, void* stream);
+
+/*
+ * Binning stage.  No counterpart in the reference (it has one global far-to-near order,
+ * torch.argsort at :153, and loops over Gaussians :366); the keys reproduce that order per tile.
+ */
+size_t gs_scan_workspace_bytes(long long N);
+/* offsets = exclusive scan of tiles_touched; *total_dev = D; host_total (host pointer, may be
+ * NULL) receives D after a stream synchronise. */
+int gs_scan_tiles(long long N, const uint32_t* tiles_touched, uint32_t* offsets, uint32_t* total_dev,
+                  void* workspace, uint32_t* host_total, void* stream);
+/* keys[o] = tile_id << 32 | key(depth) (ascending key = descending depth), vals[o] = Gaussian
+ * index, for o in [offsets[i], offsets[i] + tiles_touched[i]), tiles in row-major order. */
+int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* offsets,
+                           const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
+                           int tile_row_begin, int tile_row_end, void* stream);
+size_t gs_sort_workspace_bytes(long long D);
+/* Stable LSD radix sort on the low `bits` bits (8 per pass).  Input in (keys_a, vals_a);
+ * *result_in_b (host int) = 1 when the sorted pairs ended in (keys_b, vals_b). */
+int gs_sort_pairs(long long D, int bits, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
+                  uint32_t* vals_b, void* workspace, size_t workspace_bytes, int* result_in_b,
+                  void* stream);
+/* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty). */
+int gs_identify_tile_ranges(long long D, int num_tiles, const uint64_t* keys, uint32_t* ranges,
+                            void* stream);
+
+/*
+ * Per-tile compositing.  Replaces splat_gaussians (gaussian_renderer/__init__.py:336-442).
+ * out_image (3,H,W) = bg + sum alpha_i c_i, out_depth (H,W), out_alpha (H,W).  aux_rgb (3,H,W),
+ * optional, receives sum alpha_i c_i without bg (needed by gs_render_bwd).  t_eps in [0,1): a pixel
+ * stops once 1 - alpha_acc < t_eps; 0 = never (the reference's exact semantics).  Only pixels of
+ * tile rows [tile_row_begin, tile_row_end) are computed and written.
+ */
+int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32_t* ranges,
+                  const uint32_t* point_list, float* out_image, float* out_depth, float* out_alpha,
+                  float* aux_rgb, float t_eps, int tile_row_begin, int tile_row_end, void* stream);
+
+/*
+ * Backward of gs_render_fwd (the reference gets it from torch autograd).  g_image (3,H,W),
+ * g_depth / g_alpha (H,W) optional.  grad_rows (N x 16 floats, 16-byte aligned) must be zero on
+ * entry and receives, per Gaussian: [0,1] d/d screen mean (pixels), [2] d/d conic a, [3] d/d each
+ * off-diagonal conic entry, [4] d/d conic d, [5] d/d opacity, [6..8] d/d rgb, [9] d/d depth.
+ * t_eps must equal the forward's.
+ */
+int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const uint32_t* point_list,
+                  const float* aux_rgb, const float* out_depth, const float* out_alpha,
+                  const float* g_image, const float* g_depth, const float* g_alpha, float* grad_rows,
+                  float t_eps, int tile_row_begin, int tile_row_end, void* stream);
+
+/*
+ * Backward of gs_preprocess_fwd: chain rule from grad_rows to the rasterizer's inputs (autograd of
+ * gaussian_renderer/__init__.py:116-149,185-334 and utils/sh_utils.py:40-96 in the reference).
+ * Any g_* may be NULL.  g_means2D (N,3) receives the densification statistic the reference's
+ * trainer reads from viewspace_points.grad (train.py:185-193, scene/gaussian_model.py:701-713):
+ * d loss / d screen mean scaled to NDC units (x W/2, y H/2, 0).  Gaussians with radii == 0 get
+ * zeros everywhere.
+ */
+int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
+                      const float* projmatrix, const float* campos, const float* means3D,
+                      const float* scales, const float* rotations, const float* cov3D_precomp,
+                      const float* shs, const float* colors_precomp, const int32_t* radii,
+                      const float* grad_rows, float* g_means3D, float* g_means2D, float* g_scales,
+                      float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
+                      float* g_colors_precomp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */

@@ -1,0 +1,53 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/gsplat.h declares, and the ctypes
+binding covers exactly that set.  No compute call is made (no GPU here)."""
+import ctypes
+import importlib
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "gsplat.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_is_valid_c():
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER])
+
+
+def test_library_exports_every_declared_symbol():
+    lib_mod = importlib.import_module("gaussian-splatting_amd._lib")
+    assert os.path.exists(lib_mod.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(lib_mod.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gsplat.h but not exported"
+    assert sorted(lib_mod.PROTOTYPES) == names, "ctypes prototypes and header disagree"
+
+
+def test_housekeeping_calls_work_without_a_gpu():
+    lib = importlib.import_module("gaussian-splatting_amd._lib").load()
+    assert lib.gs_version() >= 100
+    assert lib.gs_tile_size() == 16
+    assert lib.gs_grad_row_floats() == 16
+    assert lib.gs_scan_workspace_bytes(3_000_000) >= 4 * (3_000_000 // 4096)
+    assert lib.gs_sort_workspace_bytes(7_535_647) >= 256 * 4 * (7_535_647 // 4096)
+    # argument errors are reported through the return code + gs_last_error, never a crash
+    rc = lib.gs_identify_tile_ranges(-1, 0, None, None, None)
+    assert rc == -1 and b"bad arguments" in lib.gs_last_error()
+
+
+def test_no_oracle_in_product_path():
+    """The product package must not import, link or name the oracle (it is the checker)."""
+    pkg = os.path.join(ROOT, "gaussian-splatting_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")) and f != "Makefile":
+                text = open(os.path.join(base, f)).read()
+                assert "libgs_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

@@ -209,3 +209,24 @@ def test_errors_and_edge_shapes(dgr):
     out = rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
                cov3Ds_precomp=cov)
     assert isinstance(out, tuple) and out[0].shape == (3, 33, 47)
+
+
+def test_tile_row_bands_equal_full_frame(dgr):
+    """Tile-row sharded inference (BASELINE.json config 5 pattern): bands == single-GPU frame, bit for bit."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+    sc = syn.make_scene(30000, 16, 203, 317, seed=6)   # 13 tile rows, ragged last row
+    dev = torch.device("cuda:0")
+    inp = _scene_inputs(sc, dev)
+    settings = _scene_settings(dgr, sc, dev)
+    kw = dict(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
+              scales=inp["scales"], rotations=inp["rotations"])
+    with torch.no_grad():
+        full = dgr.GaussianRasterizer(settings)(**kw)
+        for world in (2, 8):
+            bands = [par.render_band(settings, r, world, **kw) for r in range(world)]
+            assert bands[0][3][0] == 0 and bands[-1][3][1] == sc.H
+            for i, name in ((0, "image"), (1, "depth"), (2, "alpha")):
+                cat = torch.cat([b[i] for b in bands], dim=1)
+                ref = full[{0: 0, 1: 2, 2: 3}[i]]
+                assert torch.equal(cat, ref), f"{name} bands differ from the full frame (world={world})"

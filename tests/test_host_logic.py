@@ -1,0 +1,79 @@
+"""CPU-only tests of the host-side mirror of the reference interface (no kernels run)."""
+import importlib
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dgr():
+    import diff_gaussian_rasterization as m
+    return m
+
+
+def _settings(dgr, **kw):
+    base = dict(image_height=32, image_width=48, tanfovx=0.5, tanfovy=0.4, bg=torch.zeros(3), scale_modifier=1.0,
+                viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=3, campos=torch.zeros(3),
+                prefiltered=False, debug=False)
+    base.update(kw)
+    return dgr.GaussianRasterizationSettings(**base)
+
+
+def test_settings_accepts_reference_kwargs(dgr):
+    s = _settings(dgr, antialiasing=True)     # the adapter passes it (gaussian_renderer/__init__.py:576)
+    assert s.antialiasing is True and s.image_height == 32 and s.sh_degree == 3
+    with pytest.raises(TypeError):            # unknown keyword -> TypeError, like any Python callable
+        _settings(dgr, not_a_field=1)
+
+
+def test_argument_validation(dgr):
+    r = dgr.GaussianRasterizer(raster_settings=_settings(dgr))
+    m, sh, op = torch.zeros(4, 3), torch.zeros(4, 16, 3), torch.zeros(4, 1)
+    sc, q = torch.ones(4, 3), torch.zeros(4, 4)
+    with pytest.raises(ValueError):
+        r(means3D=m, means2D=None, shs=sh, colors_precomp=torch.zeros(4, 3), opacities=op, scales=sc, rotations=q)
+    with pytest.raises(ValueError):
+        r(means3D=m, means2D=None, shs=None, colors_precomp=None, opacities=op, scales=sc, rotations=q)
+    with pytest.raises(ValueError):
+        r(means3D=m, means2D=None, shs=sh, opacities=op, scales=sc, rotations=q, cov3D_precomp=torch.zeros(4, 6))
+    with pytest.raises(ValueError):
+        r(means3D=m, means2D=None, shs=sh, opacities=op)
+    with pytest.raises(ValueError):   # degree 3 needs 16 coefficients
+        r(means3D=m, means2D=None, shs=torch.zeros(4, 4, 3), opacities=op, scales=sc, rotations=q)
+    # CPU tensors: refused loudly, never a silent fallback, never TypeError (the adapter would retry)
+    with pytest.raises(RuntimeError, match="GPU"):
+        r(means3D=m, means2D=None, shs=sh, opacities=op, scales=sc, rotations=q)
+
+
+def test_synthetic_scene_is_deterministic():
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    a, b = syn.make_scene(100, 16, 40, 60, seed=3), syn.make_scene(100, 16, 40, 60, seed=3)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs", "G"):
+        assert torch.equal(getattr(a, k), getattr(b, k))
+    assert float(a.opacities.min()) >= 0.01 and float(a.opacities.max()) <= 0.99
+    assert torch.allclose(a.rotations.norm(dim=1), torch.ones(100), atol=1e-6)
+    v = syn.jitter_view(a, 1)
+    assert torch.equal(v.means3D, a.means3D) and not torch.equal(v.viewmatrix, a.viewmatrix)
+    assert torch.allclose(v.viewmatrix[:3, 3], -v.campos)
+
+
+def test_partition_helpers():
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+    for rows, world in ((135, 8), (53, 8), (7, 8), (13, 2), (1, 1)):
+        bands = [par.tile_row_band(rows, r, world) for r in range(world)]
+        assert bands[0][0] == 0 and bands[-1][1] == rows
+        assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+        sizes = [e - b for b, e in bands]
+        assert max(sizes) - min(sizes) <= 1
+    assert par.tile_row_band(135, 0, 8) == (0, 17) and par.tile_row_band(135, 7, 8) == (119, 135)
+    assert sorted(sum((par.shard_views(8, r, 3) for r in range(3)), [])) == list(range(8))
+
+
+def test_byte_model_matches_survey():
+    import bench
+    b = bench.bytes_v1(3_000_000, 2_539_666, 7_535_647, 1297 * 840, 16, 82 * 53, 6)
+    assert abs(sum(b.values()) / 1e9 - 4.99) < 0.02          # ~4.99 GB / frame
+    assert round(b["radix_sort"] / 1e6) == 1145 and round(b["render_bwd"] / 1e6) == 788

@@ -171,45 +171,63 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     }
 }
 
-// Sum each of the 10 values over the 64 lanes; totals are valid in lane 63.
-__device__ __forceinline__ void wave_sum10_to_lane63(float (&v)[10]) {
-#define GS_DPP_ADD(x, ctrl) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, true))
-#pragma unroll
-    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x111);  // row_shr:1
-#pragma unroll
-    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x112);  // row_shr:2
-#pragma unroll
-    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x114);  // row_shr:4
-#pragma unroll
-    for (int i = 0; i < 10; ++i) GS_DPP_ADD(v[i], 0x118);  // row_shr:8 -> lane 15 of each row = row total
-#undef GS_DPP_ADD
-    // row_bcast:15 into rows 1,3 then row_bcast:31 into rows 2,3 (hipcc does not fuse these from the
-    // builtin; the leading s_nop covers the VALU-write -> DPP-read hazard, later reads are >= 9 apart)
+// Transposing wave reduction of 10 values (registers only, 29 VALU instead of 60-70 for ten
+// separate butterfly reductions): every step adds the partner lane's copy AND halves the number
+// of values a lane still carries (reduce-scatter), so the work shrinks 10 -> 5 -> 3 -> 2 -> 1.
+//   step A  lane^1  quad_perm:[1,0,3,2]   keep v[j] (even lanes) or v[j+5] (odd lanes)
+//   step B  lane^2  quad_perm:[2,3,0,1]   keep by lane bit 1
+//   step C  lane^8  row_ror:8             selection by bank_mask (banks = groups of 4 lanes): free
+//   step D  lane^4  row_shl:4 / row_shr:4 per bank: free
+//   then v_permlane16_swap / v_permlane32_swap fold the four 16-lane rows lane-wise.
+// Result: every lane with (lane & 15) == k, in particular lane 48 + k, holds the 64-lane total of value GS_RED_VALUE_OF_LANE[k]:
+//   k: 0->v0 1->v5 2->v3 3->v8 4->v2 5->v7 8->v1 9->v6 10->v4 11->v9   (k = 6,7,12..15: duplicates)
+// s_nop: a DPP operand needs 2 wait states after the VALU write of that register.
+__device__ __forceinline__ float wave_reduce_scatter10(float (&v)[10], bool odd, bool bit1) {
+    float t0, out;
+    // step A: every register += its lane^1 copy
     asm volatile(
         "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %9, %9, %9 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
           "+v"(v[8]), "+v"(v[9]));
+    float a0 = odd ? v[5] : v[0], a1 = odd ? v[6] : v[1], a2 = odd ? v[7] : v[2], a3 = odd ? v[8] : v[3],
+          a4 = odd ? v[9] : v[4];
+    // step B: += lane^2 copy
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
+    float b0 = bit1 ? a3 : a0, b1 = bit1 ? a4 : a1;
+    // step C (lane^8, selection by bank_mask) and step D (lane^4, per bank)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "s_nop 1"
+        : "=&v"(t0), "=&v"(out), "+v"(b0), "+v"(b1), "+v"(a2));
+    // fold the four 16-lane rows lane-wise (row_bcast would mix lanes that carry different values)
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(out), __float_as_uint(out), false, false);
+    const float s = __uint_as_float(r.x) + __uint_as_float(r.y);
+    const u2 q = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(q.x) + __uint_as_float(q.y);
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
@@ -244,6 +262,14 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     }
     float A = 0.f, prefix = 0.f;
     bool done = !c.inside;
+    // which float of the 12-float row this lane stores after wave_reduce_scatter10 (-1: none)
+    int red_slot = -1;
+    if (lane >= 48) {
+        // k:    0 1 2 3 4 5 6  7 8 9 10 11 12..15   (one nibble per k, 0xF = none; 10 = flag slot)
+        // slot: 0 5 3 8 2 7 10 - 1 6 4  9  -
+        const int nib = (int)((0xFFFF9461FA728350ull >> (4 * (lane - 48))) & 0xF);
+        red_slot = nib == 0xF ? -1 : nib;
+    }
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(done)) break;
         const int n = min((int)(range.y - base), BATCH);
@@ -290,13 +316,9 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                 v[9] = alpha * gz;
                 A += alpha;
                 done = done || (1.0f - A) < t_eps;
-                wave_sum10_to_lane63(v);
-                if (lane == 63) {
-                    f4* a = acc_all[wave][c0 + kk];
-                    a[0] = (f4){v[0], v[1], v[2], v[3]};
-                    a[1] = (f4){v[4], v[5], v[6], v[7]};
-                    a[2] = (f4){v[8], v[9], 1.0f, 0.0f};
-                }
+                const float red = wave_reduce_scatter10(v, (lane & 1) != 0, (lane & 2) != 0);
+                // lanes 48.. hold the totals; lane 54 (a duplicate) carries the "written" flag instead
+                if (red_slot >= 0) ((float*)&acc_all[wave][c0 + kk][0])[red_slot] = (lane == 54) ? 1.0f : red;
             }
         }
         __syncthreads();

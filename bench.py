@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (preprocess -> scan -> keys -> radix sort -> ranges ->
+One "step" = one pass of the hot path (preprocess -> depth sort -> scan -> keys -> tile sort -> ranges ->
 render forward -> render backward -> preprocess backward) over one synthetic frame per GPU
 (SURVEY.md 8d generator, config 3), inputs already resident in HBM.  With N > 1 every rank
 renders its own camera view of the same replicated Gaussians and the per-Gaussian gradients are
@@ -50,6 +50,12 @@ def bytes_v1(N, V, D, P, K, tiles, passes):
         "render_bwd": 60 * D + 32 * P + 40 * D,
         "preprocess_bwd": (40 + inb + 60) * V + inb * N,
     }
+
+
+def bytes_depth_sort(N):
+    """Per-Gaussian depth pre-sort (not in the v1 model: it replaces 4 of radix_sort's 6 passes over D
+    by 4 passes over N): 4 B histogram read + 8 B read + 8 B written per Gaussian and pass."""
+    return 4 * 20 * N
 
 
 def main():
@@ -147,16 +153,17 @@ def main():
         passes = (32 + max(1, (tiles - 1).bit_length()) + 7) // 8
         b = bytes_v1(N, V, D, W * H, K, tiles, passes)
         stage_of = {"render_bwd": "render_bwd", "render_fwd": "render_fwd", "preprocess_fwd": "preprocess_fwd",
-                    "preprocess_bwd": "preprocess_bwd", "sort_pairs": "radix_sort",
+                    "preprocess_bwd": "preprocess_bwd", "sort_pairs": "radix_sort", "sort_depth": "depth_sort",
                     "duplicate_with_keys": "duplicate_with_keys", "scan_tiles": "scan",
                     "identify_tile_ranges": "identify_ranges"}
         dominant = max(stage_ms, key=stage_ms.get)
+        frame_bytes = sum(b.values())          # SURVEY.md 8d v1 model, unchanged by the depth pre-sort
+        b["depth_sort"] = bytes_depth_sort(N)
         dom_bytes = b[stage_of[dominant]]
         achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4)}
-        frame_bytes = sum(b.values())
         out = {
             "metric": "Mpix/s fwd+bwd @3M Gaussians SH3", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

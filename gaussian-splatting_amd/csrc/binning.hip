@@ -13,13 +13,17 @@
 namespace {
 
 __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int tiles_x, int row_b, int row_e,
+                                                                   const uint32_t* __restrict__ order,
                                                                    const float4* __restrict__ splat,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ tiles_touched,
                                                                    uint64_t* __restrict__ keys,
                                                                    uint32_t* __restrict__ vals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    // with `order` (Gaussian ids far-to-near) lane r emits the Gaussian of depth rank r at
+    // offsets[r], so the emitted list is already sorted on the low 32 key bits
+    const int i = order ? (int)order[r] : r;
     if (tiles_touched[i] == 0) return;
     const float4 q1 = splat[3 * (size_t)i + 1];
     const float4 q2 = splat[3 * (size_t)i + 2];
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int til
     ty0 = ty0 > row_b ? ty0 : row_b;
     ty1 = ty1 < row_e ? ty1 : row_e;
     const uint32_t dk = gs_depth_key_desc(q1.z);
-    size_t o = offsets[i];
+    size_t o = offsets[r];
     for (int ty = ty0; ty < ty1; ++ty)
         for (int tx = tx0; tx < tx1; ++tx) {
             keys[o] = ((uint64_t)(uint32_t)(ty * tiles_x + tx) << 32) | dk;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, 
 
 }  // namespace
 
-extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* offsets,
+extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
                                       const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
                                       int tile_row_begin, int tile_row_end, void* stream_) {
     GS_REQUIRE(N >= 0 && W > 0, "bad arguments");
@@ -58,7 +62,7 @@ extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uin
     GS_REQUIRE(splat && offsets && tiles_touched && keys && vals, "null buffer");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream_, N,
-                       tiles_x, tile_row_begin, tile_row_end, (const float4*)splat, offsets, tiles_touched, keys, vals);
+                       tiles_x, tile_row_begin, tile_row_end, order, (const float4*)splat, offsets, tiles_touched, keys, vals);
     GS_CHECK_LAUNCH("duplicate_with_keys");
     return GS_OK;
 }

@@ -234,13 +234,18 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ rots,
     const float* __restrict__ cov6, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
-    float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched) {
+    float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     Geom g;
     project_gaussian(i, H, W, row_b, row_e, view, proj, means3D, scales, rots, cov6, g);
     radii[i] = g.radius;
     tiles_touched[i] = g.tiles;
+    if (depth_keys) {   // input of the per-Gaussian depth sort; culled Gaussians sort last
+        depth_keys[i] = g.drawn ? gs_depth_key_desc(g.cam[2]) : 0xFFFFFFFFu;
+        ids[i] = (uint32_t)i;
+    }
     if (!g.drawn) return;
     float rgb[3];
     if (colors_precomp) {
@@ -467,14 +472,15 @@ template <int DEG>
 int launch_fwd(bool vec4, int N, int K, int H, int W, int row_b, int row_e, const float* view, const float* proj,
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* opac, const float* shs, const float* colors,
-               float4* splat, int32_t* radii, uint32_t* tiles, hipStream_t stream) {
+               float4* splat, int32_t* radii, uint32_t* tiles, uint32_t* depth_keys, uint32_t* ids,
+               hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
     if (vec4)
         hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
-                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles);
+                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids);
     else
         hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
-                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles);
+                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids);
     GS_CHECK_LAUNCH("preprocess_fwd");
     return GS_OK;
 }
@@ -518,14 +524,15 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
                                  const float* projmatrix, const float* campos, const float* means3D,
                                  const float* scales, const float* rotations, const float* cov3D_precomp,
                                  const float* opacities, const float* shs, const float* colors_precomp,
-                                 void* splat, int32_t* radii, uint32_t* tiles_touched, int tile_row_begin,
-                                 int tile_row_end, void* stream_) {
+                                 void* splat, int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
+                                 uint32_t* ids, int tile_row_begin, int tile_row_end, void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
     GS_REQUIRE(viewmatrix && projmatrix && campos && opacities && splat && radii && tiles_touched, "null argument");
     GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
     GS_REQUIRE(((uintptr_t)splat & 15) == 0, "splat buffer must be 16-byte aligned");
+    GS_REQUIRE((depth_keys == nullptr) == (ids == nullptr), "depth_keys and ids go together");
     GS_REQUIRE(tile_row_begin >= 0 && tile_row_end >= tile_row_begin, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -533,10 +540,10 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
     const int deg = shs ? sh_degree : 0;
     float4* sp = (float4*)splat;
     switch (deg) {
-        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
-        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
-        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
-        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, stream);
+        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
+        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
+        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
+        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
     }
 }
 

@@ -2,7 +2,11 @@
 // No counterpart in the reference (torch.argsort at gaussian_renderer/__init__.py:153 is the only
 // ordering it has); the result is bit-exact against oracle/gs_oracle.c::gso_sort_pairs.
 //
-// 8 bits per pass, only the significant bits (32 depth bits + ceil(log2(tiles)) tile bits).
+// 8 bits per pass over a caller-given bit range.  Two uses per frame: (1) 32-bit depth keys of the
+// N Gaussians (4 passes over N items) and (2) the 64-bit tile|depth keys of the D pairs on the
+// tile bits only (2 passes): pairs are emitted in depth order, so they are already sorted on the
+// low 32 bits and a stable sort of the tile bits alone yields exactly the order a full 45-bit
+// sort would (the full sort is still available: bit_begin = 0).
 // Per pass:
 //   1. histogram: each workgroup counts the digits of its 4096-key tile (wave64 ballot "match":
 //      one LDS add per distinct digit per wave, so skewed tile digits cost the same as random ones);
@@ -39,7 +43,8 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return (1ull << lane) - 1ull;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t* __restrict__ keys, long long D,
+template <typename KeyT>
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const KeyT* __restrict__ keys, long long D,
                                                                  int shift, int nblocks,
                                                                  uint32_t* __restrict__ table) {
     __shared__ uint32_t hist[RS_RADIX];
@@ -59,10 +64,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t* 
     table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
 }
 
+template <typename KeyT>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, long long D, int shift, int nblocks, const uint32_t* __restrict__ table) {
-    __shared__ uint64_t skeys[RS_TILE];
+    __shared__ KeyT skeys[RS_TILE];
     __shared__ uint32_t svals[RS_TILE];
     __shared__ uint32_t wave_cnt[RS_WAVES][RS_RADIX];
     __shared__ uint32_t digit_base[RS_RADIX];
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 
     const long long block_base = (long long)blockIdx.x * RS_TILE;
     const long long base = block_base + (long long)wave * 64 * RS_ITEMS;
-    uint64_t key[RS_ITEMS];
+    KeyT key[RS_ITEMS];
     uint32_t val[RS_ITEMS];
     uint32_t rank[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     for (int it = 0; it < RS_ITEMS; ++it) {
         const long long idx = base + it * 64 + lane;
         const bool valid = idx < D;
-        key[it] = valid ? keys_in[idx] : ~0ull;
+        key[it] = valid ? keys_in[idx] : (KeyT)~(KeyT)0;
         val[it] = valid ? vals_in[idx] : 0u;
     }
 #pragma unroll
@@ -146,13 +152,56 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int p = j * RS_THREADS + tid;
         if (p < count) {
-            const uint64_t k = skeys[p];
+            const KeyT k = skeys[p];
             const uint32_t d = (uint32_t)(k >> shift) & 0xFFu;
             const uint32_t o = (uint32_t)p + gofs[d];
             keys_out[o] = k;
             vals_out[o] = svals[p];
         }
     }
+}
+
+}  // namespace
+
+extern "C" size_t gs_sort_workspace_bytes(long long D);
+
+namespace {
+
+template <typename KeyT>
+int sort_pairs_impl(long long D, int bit_begin, int bit_end, KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b,
+                    uint32_t* vals_b, void* workspace, size_t workspace_bytes, int* result_in_b,
+                    hipStream_t stream) {
+    GS_REQUIRE(D >= 0 && D < (1ll << 32) && result_in_b, "bad arguments");
+    GS_REQUIRE(bit_begin >= 0 && bit_begin <= bit_end && bit_end <= (int)(8 * sizeof(KeyT)), "bad bit range [%d,%d)",
+               bit_begin, bit_end);
+    *result_in_b = 0;
+    if (D == 0 || bit_begin == bit_end) return GS_OK;
+    GS_REQUIRE(keys_a && vals_a && keys_b && vals_b && workspace, "null buffer");
+    GS_REQUIRE(workspace_bytes >= gs_sort_workspace_bytes(D), "sort workspace too small");
+    GS_REQUIRE(((uintptr_t)workspace & 15) == 0, "sort workspace must be 16-byte aligned");
+    const int nblocks = (int)((D + RS_TILE - 1) / RS_TILE);
+    const long long table_n = (long long)nblocks * RS_RADIX;
+    uint32_t* table = (uint32_t*)workspace;
+    size_t tb = ((size_t)table_n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    void* scan_ws = (char*)workspace + tb;
+    KeyT *ks = keys_a, *kd = keys_b;
+    uint32_t *vs = vals_a, *vd = vals_b;
+    int passes = 0;
+    for (int shift = bit_begin; shift < bit_end; shift += 8) {
+        hipLaunchKernelGGL((radix_hist_kernel<KeyT>), dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, D, shift,
+                           nblocks, table);
+        GS_CHECK_LAUNCH("radix_hist");
+        int rc = gs_exclusive_scan_u32(table, table, table_n, nullptr, nullptr, scan_ws, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL((radix_scatter_kernel<KeyT>), dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd,
+                           D, shift, nblocks, table);
+        GS_CHECK_LAUNCH("radix_scatter");
+        KeyT* tk = ks; ks = kd; kd = tk;
+        uint32_t* tv = vs; vs = vd; vd = tv;
+        ++passes;
+    }
+    *result_in_b = passes & 1;
+    return GS_OK;
 }
 
 }  // namespace
@@ -165,38 +214,19 @@ extern "C" size_t gs_sort_workspace_bytes(long long D) {
     return bytes + gs_scan_ws_bytes(table) + 256;
 }
 
-// Sorts on the low `bits` bits.  keys_a/vals_a hold the input; *result_in_b tells which buffer pair
-// holds the sorted output (b after an odd number of passes).
-extern "C" int gs_sort_pairs(long long D, int bits, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
-                             uint32_t* vals_b, void* workspace, size_t workspace_bytes, int* result_in_b,
-                             void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GS_REQUIRE(D >= 0 && D < (1ll << 32) && bits > 0 && bits <= 64 && result_in_b, "bad arguments");
-    *result_in_b = 0;
-    if (D == 0) return GS_OK;
-    GS_REQUIRE(keys_a && vals_a && keys_b && vals_b && workspace, "null buffer");
-    GS_REQUIRE(workspace_bytes >= gs_sort_workspace_bytes(D), "sort workspace too small");
-    GS_REQUIRE(((uintptr_t)workspace & 15) == 0, "sort workspace must be 16-byte aligned");
-    const int nblocks = (int)((D + RS_TILE - 1) / RS_TILE);
-    const long long table_n = (long long)nblocks * RS_RADIX;
-    uint32_t* table = (uint32_t*)workspace;
-    size_t tb = ((size_t)table_n * sizeof(uint32_t) + 255) & ~(size_t)255;
-    void* scan_ws = (char*)workspace + tb;
-    uint64_t *ks = keys_a, *kd = keys_b;
-    uint32_t *vs = vals_a, *vd = vals_b;
-    int passes = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, D, shift, nblocks, table);
-        GS_CHECK_LAUNCH("radix_hist");
-        int rc = gs_exclusive_scan_u32(table, table, table_n, nullptr, scan_ws, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd, D,
-                           shift, nblocks, table);
-        GS_CHECK_LAUNCH("radix_scatter");
-        uint64_t* tk = ks; ks = kd; kd = tk;
-        uint32_t* tv = vs; vs = vd; vd = tv;
-        ++passes;
-    }
-    *result_in_b = passes & 1;
-    return GS_OK;
+// Stable sort of (uint64 key, uint32 value) pairs on key bits [bit_begin, bit_end).  keys_a/vals_a hold
+// the input; *result_in_b tells which buffer pair holds the output (b after an odd number of passes).
+extern "C" int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint64_t* keys_a, uint32_t* vals_a,
+                             uint64_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
+                             int* result_in_b, void* stream_) {
+    return sort_pairs_impl<uint64_t>(D, bit_begin, bit_end, keys_a, vals_a, keys_b, vals_b, workspace,
+                                     workspace_bytes, result_in_b, (hipStream_t)stream_);
+}
+
+// Same for uint32 keys (the per-Gaussian depth sort).
+extern "C" int gs_sort_pairs32(long long D, int bit_begin, int bit_end, uint32_t* keys_a, uint32_t* vals_a,
+                               uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
+                               int* result_in_b, void* stream_) {
+    return sort_pairs_impl<uint32_t>(D, bit_begin, bit_end, keys_a, vals_a, keys_b, vals_b, workspace,
+                                     workspace_bytes, result_in_b, (hipStream_t)stream_);
 }

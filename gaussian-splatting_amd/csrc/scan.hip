@@ -39,7 +39,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wa
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, long long n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in,
+                                                                    const uint32_t* __restrict__ gather, long long n,
                                                                     uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
     const long long base = (long long)blockIdx.x * SCAN_TILE;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         const long long idx = base + (long long)j * SCAN_THREADS + threadIdx.x;  // coalesced
-        if (idx < n) s += in[idx];
+        if (idx < n) s += gather ? in[gather[idx]] : in[idx];
     }
     uint32_t total;
     block_excl_scan(s, lds_wave, total);
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
 }
 
 // in == out is allowed (each lane reads its 16 elements before it writes them)
-__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t* in, long long n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t* in,
+                                                                   const uint32_t* __restrict__ gather, long long n,
                                                                    const uint32_t* __restrict__ block_sums,
                                                                    uint32_t* out) {
     __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
@@ -79,7 +81,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t
     const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
-    if (base + SCAN_ITEMS <= n) {
+    if (gather) {   // out[i] = exclusive scan of in[gather[i]] (scan in sorted order)
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? in[gather[base + j]] : 0u;
+    } else if (base + SCAN_ITEMS <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(in + base);
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS / 4; ++j) {
@@ -121,8 +126,8 @@ size_t gs_scan_ws_bytes(long long n) {
     return (size_t)(nblocks + 1) * sizeof(uint32_t);
 }
 
-int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32_t* total_out, void* ws,
-                          hipStream_t stream) {
+int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32_t* total_out,
+                          const uint32_t* gather, void* ws, hipStream_t stream) {
     if (n <= 0) {
         if (total_out) GS_CHECK_HIP(hipMemsetAsync(total_out, 0, sizeof(uint32_t), stream));
         return GS_OK;
@@ -130,11 +135,11 @@ int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32
     GS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "scan buffers must be 16-byte aligned");
     const int nblocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     uint32_t* sums = (uint32_t*)ws;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, gather, n, sums);
     GS_CHECK_LAUNCH("scan_reduce");
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks, total_out);
     GS_CHECK_LAUNCH("scan_sums");
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, n, sums, out);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, gather, n, sums, out);
     GS_CHECK_LAUNCH("scan_final");
     return GS_OK;
 }
@@ -143,12 +148,12 @@ int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32
 // when host_total is given, synchronously to the host.
 extern "C" size_t gs_scan_workspace_bytes(long long n) { return gs_scan_ws_bytes(n); }
 
-extern "C" int gs_scan_tiles(long long N, const uint32_t* tiles_touched, uint32_t* offsets,
+extern "C" int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
                              uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GS_REQUIRE(N >= 0 && total_dev, "bad arguments");
     GS_REQUIRE(N == 0 || (tiles_touched && offsets && workspace), "null buffer");
-    int rc = gs_exclusive_scan_u32(tiles_touched, offsets, N, total_dev, workspace, stream);
+    int rc = gs_exclusive_scan_u32(tiles_touched, offsets, N, total_dev, order, workspace, stream);
     if (rc) return rc;
     if (host_total) {
         GS_CHECK_HIP(hipMemcpyAsync(host_total, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -61,7 +61,8 @@ class BinningState(NamedTuple):
     splat: torch.Tensor          # (N,12) f32 splat records (see csrc/gsplat_common.h)
     radii: torch.Tensor          # (N,) i32
     tiles_touched: torch.Tensor  # (N,) u32 as i32 storage
-    offsets: torch.Tensor        # (N,) exclusive scan
+    order: torch.Tensor          # (N,) Gaussian ids far-to-near (culled ones last), stable in the index
+    offsets: torch.Tensor        # (N,) exclusive scan of tiles_touched[order]
     num_pairs: int               # D
     keys: torch.Tensor           # (D,) sorted 64-bit keys (int64 storage)
     point_list: torch.Tensor     # (D,) Gaussian index per sorted pair (int32 storage)
@@ -116,7 +117,7 @@ def _band(settings, tile_rows):
 
 def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
                        cov3D_precomp, shs, colors_precomp, tile_rows=None) -> BinningState:
-    """preprocess -> scan -> duplicate_with_keys -> radix sort -> tile ranges (all on the current stream)."""
+    """preprocess -> depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges (current stream)."""
     lib = _lib.load()
     dev = means3D.device
     N = means3D.shape[0]
@@ -131,18 +132,29 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
     radii = torch.empty((N,), **i32)
     tiles_touched = torch.empty((N,), **i32)
+    # depth keys / Gaussian ids, ping-pong buffers of the per-Gaussian depth sort
+    dkeys = torch.empty((2, max(N, 1)), **i32)
+    ids = torch.empty((2, max(N, 1)), **i32)
     with _stage("preprocess_fwd"):
         _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
-                                         _ptr(radii), _ptr(tiles_touched), row_b, row_e, st), "gs_preprocess_fwd")
+                                         _ptr(radii), _ptr(tiles_touched), _ptr(dkeys[0]), _ptr(ids[0]),
+                                         row_b, row_e, st), "gs_preprocess_fwd")
+    in_b = C.c_int(0)
+    ws_bytes = lib.gs_sort_workspace_bytes(N)
+    sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
+    with _stage("sort_depth"):
+        _lib.check(lib.gs_sort_pairs32(N, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
+                                       _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs32")
+    order = ids[1 if in_b.value else 0][:N]
     offsets = torch.empty((N,), **i32)
     total = torch.empty((1,), **i32)
     scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
     host_total = C.c_uint32(0)
     with _stage("scan_tiles"):
-        _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(offsets), _ptr(total), _ptr(scan_ws),
-                                     C.byref(host_total), st), "gs_scan_tiles")
+        _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
+                                     _ptr(scan_ws), C.byref(host_total), st), "gs_scan_tiles")
     D = int(host_total.value)
     tiles_x, tiles_y = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     ntiles = tiles_x * tiles_y
@@ -151,21 +163,21 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     vals_a = torch.empty((max(D, 1),), **i32)
     vals_b = torch.empty((max(D, 1),), **i32)
     with _stage("duplicate_with_keys"):
-        _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(offsets), _ptr(tiles_touched),
+        _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(order), _ptr(offsets), _ptr(tiles_touched),
                                               _ptr(keys_a), _ptr(vals_a), row_b, row_e, st),
                    "gs_duplicate_with_keys")
+    # pairs were emitted far-to-near, so only the tile bits are left to sort (stable)
     bits = 32 + max(1, (ntiles - 1).bit_length())
     ws_bytes = lib.gs_sort_workspace_bytes(D)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
-    in_b = C.c_int(0)
     with _stage("sort_pairs"):
-        _lib.check(lib.gs_sort_pairs(D, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+        _lib.check(lib.gs_sort_pairs(D, 32, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
                                      _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     keys, point_list = (keys_b, vals_b) if in_b.value else (keys_a, vals_a)
     ranges = torch.empty((ntiles, 2), **i32)
     with _stage("identify_tile_ranges"):
         _lib.check(lib.gs_identify_tile_ranges(D, ntiles, _ptr(keys), _ptr(ranges), st), "gs_identify_tile_ranges")
-    return BinningState(splat, radii, tiles_touched, offsets, D, keys[:D], point_list[:D], ranges)
+    return BinningState(splat, radii, tiles_touched, order, offsets, D, keys[:D], point_list[:D], ranges)
 
 
 class _RasterizeGaussians(torch.autograd.Function):

@@ -54,35 +54,45 @@ int gs_grad_row_floats(void);    /* 16: floats per per-Gaussian gradient row (se
  * BASELINE.json config 5); radii are independent of the band.
  * Outputs: splat (N x 12 floats, 48-byte records, layout in csrc/gsplat_common.h; rows of culled
  * Gaussians are not written), radii (N) int32 = ceil(3 sigma_max) or 0 when not drawn,
- * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.
+ * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.  depth_keys / ids (N each,
+ * both or neither NULL): input of the per-Gaussian depth sort, depth_keys[i] = key(depth) as in
+ * gs_duplicate_with_keys (0xFFFFFFFF for Gaussians that are not drawn, so they sort last), ids[i] = i.
  */
 int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                       const float* projmatrix, const float* campos, const float* means3D,
                       const float* scales, const float* rotations, const float* cov3D_precomp,
                       const float* opacities, const float* shs, const float* colors_precomp,
-                      void* splat, int32_t* radii, uint32_t* tiles_touched, int tile_row_begin,
-                      int tile_row_end, void* stream);
+                      void* splat, int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
+                      uint32_t* ids, int tile_row_begin, int tile_row_end, void* stream);
 
 /*
  * Binning stage.  No counterpart in the reference (it has one global far-to-near order,
  * torch.argsort at :153, and loops over Gaussians :366); the keys reproduce that order per tile.
  */
 size_t gs_scan_workspace_bytes(long long N);
-/* offsets = exclusive scan of tiles_touched; *total_dev = D; host_total (host pointer, may be
- * NULL) receives D after a stream synchronise. */
-int gs_scan_tiles(long long N, const uint32_t* tiles_touched, uint32_t* offsets, uint32_t* total_dev,
-                  void* workspace, uint32_t* host_total, void* stream);
+/* offsets[r] = exclusive scan of tiles_touched[order[r]] (order == NULL: of tiles_touched[r]);
+ * *total_dev = D; host_total (host pointer, may be NULL) receives D after a stream synchronise. */
+int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
+                  uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream);
 /* keys[o] = tile_id << 32 | key(depth) (ascending key = descending depth), vals[o] = Gaussian
- * index, for o in [offsets[i], offsets[i] + tiles_touched[i]), tiles in row-major order. */
-int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* offsets,
+ * index i = order[r] (order == NULL: i = r), for o in [offsets[r], offsets[r] + tiles_touched[i]),
+ * tiles in row-major order.  With `order` = the Gaussian ids sorted by depth key (gs_sort_pairs32)
+ * the emitted list is already sorted on the low 32 key bits. */
+int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
                            const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
                            int tile_row_begin, int tile_row_end, void* stream);
 size_t gs_sort_workspace_bytes(long long D);
-/* Stable LSD radix sort on the low `bits` bits (8 per pass).  Input in (keys_a, vals_a);
- * *result_in_b (host int) = 1 when the sorted pairs ended in (keys_b, vals_b). */
-int gs_sort_pairs(long long D, int bits, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
-                  uint32_t* vals_b, void* workspace, size_t workspace_bytes, int* result_in_b,
-                  void* stream);
+/* Stable LSD radix sort on key bits [bit_begin, bit_end) (8 per pass).  Input in (keys_a, vals_a);
+ * *result_in_b (host int) = 1 when the sorted pairs ended in (keys_b, vals_b).  The frame pipeline
+ * sorts the N (depth key, id) pairs on all 32 bits with gs_sort_pairs32 -- the reference's one
+ * global far-to-near order, torch.argsort at :153 -- and the D (tile|depth, id) pairs on the tile
+ * bits [32, 32 + tile_bits) only. */
+int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint64_t* keys_a, uint32_t* vals_a,
+                  uint64_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
+                  int* result_in_b, void* stream);
+int gs_sort_pairs32(long long D, int bit_begin, int bit_end, uint32_t* keys_a, uint32_t* vals_a,
+                    uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
+                    int* result_in_b, void* stream);
 /* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty). */
 int gs_identify_tile_ranges(long long D, int num_tiles, const uint64_t* keys, uint32_t* ranges,
                             void* stream);

@@ -91,6 +91,12 @@ def test_integer_stage_bit_exact_vs_oracle(dgr, oracle, name):
     _compare_binning(st, geom, ob)
 
 
+def _sortable(depth):
+    """float -> uint32 whose unsigned order is the float order (csrc/gsplat_common.h gs_depth_key_desc = ~this)."""
+    b = np.ascontiguousarray(depth, dtype=np.float32).view(np.uint32)
+    return np.where(b >> 31, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
+
+
 def _compare_binning(st, geom, ob):
     radii = st.radii.cpu().numpy()
     tiles = st.tiles_touched.cpu().numpy().view(np.uint32)
@@ -107,7 +113,14 @@ def _compare_binning(st, geom, ob):
     assert np.array_equal(sp[drawn, 6], geom.depth[drawn]), "depths differ"
     assert np.array_equal(sp[drawn][:, [2, 3, 4]], geom.conic[drawn]), "conics differ"
     np.testing.assert_allclose(sp[drawn, 8:11], geom.rgb[drawn], rtol=0, atol=2e-6)
-    assert np.array_equal(st.offsets.cpu().numpy().view(np.uint32), ob["offsets"]), "offsets differ"
+    # depth order: stable argsort of the 32-bit depth key (culled Gaussians carry 0xFFFFFFFF), then
+    # offsets = exclusive scan of tiles_touched in that order
+    dkey = np.where(drawn, ~_sortable(geom.depth), np.uint32(0xFFFFFFFF)).astype(np.uint32)
+    order = np.argsort(dkey, kind="stable").astype(np.uint32)
+    assert np.array_equal(st.order.cpu().numpy().view(np.uint32), order), "depth order differs"
+    t_ord = tiles[order].astype(np.uint64)
+    excl = (np.cumsum(t_ord) - t_ord).astype(np.uint32)
+    assert np.array_equal(st.offsets.cpu().numpy().view(np.uint32), excl), "offsets differ"
     assert st.num_pairs == ob["D"]
     assert np.array_equal(st.keys.cpu().numpy().view(np.uint64), ob["keys"]), "sorted keys differ"
     assert np.array_equal(st.point_list.cpu().numpy().view(np.uint32), ob["vals"]), "sorted values differ"

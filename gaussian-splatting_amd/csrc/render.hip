@@ -21,13 +21,20 @@
 // transmittance 1 - A drops below t_eps, a wave when all its lanes stopped (ballot), a workgroup
 // when all its waves did.  t_eps = 0 reproduces the reference exactly (no stop).
 //
-// Backward gradient accumulation: per Gaussian 10 partial sums are reduced over the wave with DPP
-// row shifts + row broadcasts (registers only); lane 63 stores the row into the wave's own LDS
-// slot (plain stores, no LDS atomics); after the batch the 4 waves' rows are summed and flushed
-// once per (tile, Gaussian) as one 40-byte row-shaped float atomic into that Gaussian's 64-byte
-// gradient row.
+// Per-visit work is trimmed at staging time (once per (tile, Gaussian) pair instead of once per
+// visit and lane): the LDS copy of a record carries the conic pre-scaled for v_exp_f32
+// (power * log2 e = A' dx^2 + B' dx dy + C' dy^2) and the box as two packed u16 pairs, so the
+// per-lane box test is v_pk_max_u16 + v_pk_min_u16 + one compare, and a stopped lane is folded
+// into the same test by setting its packed pixel coordinate to 0xFFFFFFFF.
 //
-// Bound: VALU (exp + ~25 fp32 ops per lane-visit forward, ~100 backward); HBM traffic is the
+// Backward gradient accumulation: per Gaussian 10 partial sums (the mean/conic ones as raw
+// moments sum q dx, q dy, q dx^2, q dx dy, q dy^2 with q = dL/dpower; the per-Gaussian factors are
+// applied at flush time) are reduced over the wave by a select-free reduce-scatter (25 VALU,
+// registers only); ten lanes store one dword each into the wave's own LDS slot (plain stores, no
+// LDS atomics); after the batch the 4 waves' rows are summed and flushed once per (tile, Gaussian)
+// as one 40-byte row-shaped float atomic into that Gaussian's 64-byte gradient row.
+//
+// Bound: VALU (exp + ~20 fp32 ops per lane-visit forward, ~80 backward); HBM traffic is the
 // record gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
 #include "gsplat_common.h"
 
@@ -45,6 +52,33 @@ __device__ __forceinline__ Rec load_rec(const f4* sq, int j) {
     r.q2 = sq[3 * j + 2];
     return r;
 }
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+constexpr float GS_LOG2E = 1.4426950408889634f;
+
+// LDS form of a splat record (written by stage_and_cull):
+//   q0 = (mean_x, mean_y, A', B')   q1 = (C', opacity, depth, x_min | y_min << 16)
+//   q2 = (red, green, blue, (x_max - 1) | (y_max - 1) << 16)
+// with A' = -0.5 log2e conic_a, B' = -log2e conic_b, C' = -0.5 log2e conic_d.
+__device__ __forceinline__ void to_lds_form(f4& p0, f4& p1, f4& p2) {
+    const uint32_t rx = __float_as_uint(p1.w), ry = __float_as_uint(p2.w);
+    p0.z *= -0.5f * GS_LOG2E;
+    p0.w *= -GS_LOG2E;
+    p1.x *= -0.5f * GS_LOG2E;
+    p1.w = __uint_as_float((rx & 0xFFFFu) | (ry << 16));
+    p2.w = __uint_as_float(((rx >> 16) - 1u) | (((ry >> 16) - 1u) << 16));
+}
+
+// packed pixel inside the packed inclusive box?  (2 x v_pk_{max,min}_u16 + v_cmp)
+__device__ __forceinline__ bool in_box(uint32_t P, uint32_t lo, uint32_t hi) {
+    const us2 c = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, P),
+                                                                      __builtin_bit_cast(us2, lo)),
+                                            __builtin_bit_cast(us2, hi));
+    return __builtin_bit_cast(uint32_t, c) == P;
+}
+
+constexpr uint32_t P_STOPPED = 0xFFFFFFFFu;   // never inside a box: x_max - 1 <= 65534
 
 struct TileCtx {
     int px, py;        // this lane's pixel
@@ -83,9 +117,11 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     if (tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];
         const f4* p = splat + 3 * (size_t)id;
-        sq[3 * tid] = p[0];
-        sq[3 * tid + 1] = p[1];
-        sq[3 * tid + 2] = p[2];
+        f4 p0 = p[0], p1 = p[1], p2 = p[2];
+        to_lds_form(p0, p1, p2);
+        sq[3 * tid] = p0;
+        sq[3 * tid + 1] = p1;
+        sq[3 * tid + 2] = p2;
         if (sid) sid[tid] = id;
     }
     __syncthreads();
@@ -98,9 +134,9 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         const int j = r * 64 + lane;
         bool hit = false;
         if (j < n) {
-            const uint32_t rx = squ[12 * j + 7], ry = squ[12 * j + 11];
-            const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
-            hit = xmin < c.sx0 + GS_SUB && xmax > c.sx0 && ymin < c.sy0 + GS_SUB && ymax > c.sy0;
+            const uint32_t lo = squ[12 * j + 7], hi = squ[12 * j + 11];
+            const int xmin = lo & 0xFFFF, ymin = lo >> 16, xlast = hi & 0xFFFF, ylast = hi >> 16;
+            hit = xmin < c.sx0 + GS_SUB && xlast >= c.sx0 && ymin < c.sy0 + GS_SUB && ylast >= c.sy0;
         }
         const uint64_t m = __ballot(hit);
         const int pos = count + __popcll(m & lt);
@@ -127,10 +163,10 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     uint32_t* wl = wl_all[threadIdx.x >> 6];
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
-    float A = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Z = 0.f;
-    bool done = !c.inside;
+    float A = 0.f, T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Z = 0.f;
+    uint32_t P = c.inside ? ((uint32_t)c.px | (uint32_t)c.py << 16) : P_STOPPED;
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
         const int count = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr);
         bool stop = false;
@@ -138,21 +174,20 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
             const int cn = min(64, count - c0);
             const uint32_t jv = wl[c0 + lane];
             for (int kk = 0; kk < cn; ++kk) {
-                if ((kk & 7) == 0 && __all(done)) { stop = true; break; }
+                if ((kk & 7) == 0 && __all(P == P_STOPPED)) { stop = true; break; }
                 const Rec rec = load_rec(sq, __builtin_amdgcn_readlane(jv, kk));
-                const uint32_t rx = __float_as_uint(rec.q1.w), ry = __float_as_uint(rec.q2.w);
-                const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
-                const bool act = !done && c.px >= xmin && c.px < xmax && c.py >= ymin && c.py < ymax;
+                const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
                 const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
-                const float power = -0.5f * ((rec.q0.z * dx * dx + (rec.q0.w + rec.q0.w) * dx * dy) + rec.q1.x * dy * dy);
-                const float w = __expf(power) * rec.q1.y;
-                const float alpha = act ? w * (1.0f - A) : 0.0f;
+                const float power2 = (rec.q0.z * dx + rec.q0.w * dy) * dx + (rec.q1.x * dy) * dy;
+                const float w = __builtin_amdgcn_exp2f(power2) * rec.q1.y;
+                const float alpha = act ? w * T : 0.0f;
                 Cr += alpha * rec.q2.x;
                 Cg += alpha * rec.q2.y;
                 Cb += alpha * rec.q2.z;
                 Z += alpha * rec.q1.z;
                 A += alpha;
-                done = done || (1.0f - A) < t_eps;
+                T = 1.0f - A;
+                P = T < t_eps ? P_STOPPED : P;
             }
         }
     }
@@ -171,63 +206,58 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     }
 }
 
-// Transposing wave reduction of 10 values (registers only, 29 VALU instead of 60-70 for ten
+// Select-free wave reduce-scatter of 10 values (registers only, 25 VALU instead of 60-70 for ten
 // separate butterfly reductions): every step adds the partner lane's copy AND halves the number
-// of values a lane still carries (reduce-scatter), so the work shrinks 10 -> 5 -> 3 -> 2 -> 1.
-//   step A  lane^1  quad_perm:[1,0,3,2]   keep v[j] (even lanes) or v[j+5] (odd lanes)
-//   step B  lane^2  quad_perm:[2,3,0,1]   keep by lane bit 1
-//   step C  lane^8  row_ror:8             selection by bank_mask (banks = groups of 4 lanes): free
-//   step D  lane^4  row_shl:4 / row_shr:4 per bank: free
-//   then v_permlane16_swap / v_permlane32_swap fold the four 16-lane rows lane-wise.
-// Result: every lane with (lane & 15) == k, in particular lane 48 + k, holds the 64-lane total of value GS_RED_VALUE_OF_LANE[k]:
-//   k: 0->v0 1->v5 2->v3 3->v8 4->v2 5->v7 8->v1 9->v6 10->v4 11->v9   (k = 6,7,12..15: duplicates)
+// of values a lane still carries, so the work shrinks 10 -> 5 -> 3 -> 2 -> 1.  The steps whose
+// "which half do I keep" is a DPP bank (4 lanes) or a row (16 lanes) come first, while there are
+// many values, because there the selection is free (bank_mask / permlane swap); the lane^1 and
+// lane^2 steps, which would need v_cndmask selects, come last on the single remaining value.
+//   step 1  lane^8   row_ror:8, bank_mask picks v[j] (banks 0,1) or v[j+5] (banks 2,3)
+//   step 2  lane^4   row_shl:4 / row_shr:4 per bank
+//   step 3  lane^16  v_permlane16_swap + add      step 4  lane^32  v_permlane32_swap + add
+//   step 5  quad sum quad_perm xor 1, xor 2
+// Result: all four lanes of a quad hold the 64-lane total of one value; first lane of the quad:
+//   v0:0  v1:16  v2:4  v3:20  v4:32  v5:8  v6:24  v7:12  v8:28  v9:40     (tools/dpp_test/t2.hip)
 // s_nop: a DPP operand needs 2 wait states after the VALU write of that register.
-__device__ __forceinline__ float wave_reduce_scatter10(float (&v)[10], bool odd, bool bit1) {
-    float t0, out;
-    // step A: every register += its lane^1 copy
+__device__ __forceinline__ float wave_reduce_scatter10(const float (&v)[10]) {
+    float o0, o1, o2, o3, o4, p0, p1, p2;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(p0), "=&v"(p1), "=&v"(p2)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+          "v"(v[9]));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+    const float q0 = __uint_as_float(a.x) + __uint_as_float(a.y);
+    const u2 b = __builtin_amdgcn_permlane16_swap(__float_as_uint(p2), __float_as_uint(p2), false, false);
+    const float q1 = __uint_as_float(b.x) + __uint_as_float(b.y);
+    const u2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(q0), __float_as_uint(q1), false, false);
+    float r = __uint_as_float(c.x) + __uint_as_float(c.y);
     asm volatile(
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-          "+v"(v[8]), "+v"(v[9]));
-    float a0 = odd ? v[5] : v[0], a1 = odd ? v[6] : v[1], a2 = odd ? v[7] : v[2], a3 = odd ? v[8] : v[3],
-          a4 = odd ? v[9] : v[4];
-    // step B: += lane^2 copy
-    asm volatile(
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
-    float b0 = bit1 ? a3 : a0, b1 = bit1 ? a4 : a1;
-    // step C (lane^8, selection by bank_mask) and step D (lane^4, per bank)
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %1, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
         "s_nop 1"
-        : "=&v"(t0), "=&v"(out), "+v"(b0), "+v"(b1), "+v"(a2));
-    // fold the four 16-lane rows lane-wise (row_bcast would mix lanes that carry different values)
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(out), __float_as_uint(out), false, false);
-    const float s = __uint_as_float(r.x) + __uint_as_float(r.y);
-    const u2 q = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return __uint_as_float(q.x) + __uint_as_float(q.y);
+        : "+v"(r));
+    return r;
 }
 
 __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
@@ -260,18 +290,19 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         total = (gr * aux_rgb[p] + gg * aux_rgb[HW + p] + gb * aux_rgb[2 * HW + p]) + gz * out_depth[p] +
                 ga * out_alpha[p];
     }
-    float A = 0.f, prefix = 0.f;
-    bool done = !c.inside;
-    // which float of the 12-float row this lane stores after wave_reduce_scatter10 (-1: none)
+    float A = 0.f, T = 1.f, prefix = 0.f;
+    uint32_t P = c.inside ? ((uint32_t)c.px | (uint32_t)c.py << 16) : P_STOPPED;
+    // which float of the 12-float slot this lane stores after wave_reduce_scatter10 (-1: none):
+    // value v_k = row float k; lane 36 (a duplicate of v4) carries the "written" flag, float 10
     int red_slot = -1;
-    if (lane >= 48) {
-        // k:    0 1 2 3 4 5 6  7 8 9 10 11 12..15   (one nibble per k, 0xF = none; 10 = flag slot)
-        // slot: 0 5 3 8 2 7 10 - 1 6 4  9  -
-        const int nib = (int)((0xFFFF9461FA728350ull >> (4 * (lane - 48))) & 0xF);
+    if ((lane & 3) == 0) {
+        // quad:  0 1 2 3 4 5 6 7 8 9  10 11..15   (one nibble per quad, 0xF = none)
+        // float: 0 2 5 7 1 3 6 8 4 10 9  -
+        const int nib = (int)((0xFFFFF9A486317520ull >> (4 * (lane >> 2))) & 0xF);
         red_slot = nib == 0xF ? -1 : nib;
     }
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
         // clear the "written" flags of every slot (2 per lane: NW*BATCH = 512 slots)
 #pragma unroll
@@ -283,53 +314,51 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const int cn = min(64, count - c0);
             const uint32_t jv = wl[c0 + lane];
             for (int kk = 0; kk < cn; ++kk) {
-                if ((kk & 7) == 0 && __all(done)) { stop = true; break; }
+                if ((kk & 7) == 0 && __all(P == P_STOPPED)) { stop = true; break; }
                 const Rec rec = load_rec(sq, __builtin_amdgcn_readlane(jv, kk));
-                const uint32_t rx = __float_as_uint(rec.q1.w), ry = __float_as_uint(rec.q2.w);
-                const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
-                const bool act = !done && c.px >= xmin && c.px < xmax && c.py >= ymin && c.py < ymax;
+                const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
                 if (!__any(act)) continue;   // slot keeps flag 0
-                const float ca = rec.q0.z, cb = rec.q0.w, cd = rec.q1.x, op = rec.q1.y, z = rec.q1.z;
                 const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
-                const float power = -0.5f * ((ca * dx * dx + (cb + cb) * dx * dy) + cd * dy * dy);
-                const float G = act ? __expf(power) : 0.0f;  // inactive lanes must not leak inf/NaN into the sums
-                const float w = G * op;
-                const float T = 1.0f - A;
+                const float power2 = (rec.q0.z * dx + rec.q0.w * dy) * dx + (rec.q1.x * dy) * dy;
+                const float G = act ? __builtin_amdgcn_exp2f(power2) : 0.0f;  // inactive lanes: every sum gets 0
+                const float w = G * rec.q1.y;
                 const float alpha = w * T;
-                const float u = (rec.q2.x * gr + rec.q2.y * gg + rec.q2.z * gb) + z * gz + ga;
+                const float u = (rec.q2.x * gr + rec.q2.y * gg + rec.q2.z * gb) + rec.q1.z * gz + ga;
                 prefix += u * alpha;
                 const float suffix = total - prefix;
                 const float inv = __builtin_amdgcn_rcpf(fmaxf(1.0f - w, 1e-6f));
-                const float dLdw = act ? (T * u - suffix * inv) : 0.0f;
-                const float dLdp = w * dLdw;
-                const float h = -0.5f * dLdp;
+                const float dLdw = T * u - suffix * inv;
+                const float q = w * dLdw;          // dL/dpower
+                const float qx = q * dx, qy = q * dy;
                 float v[10];
-                v[0] = dLdp * (ca * dx + cb * dy);
-                v[1] = dLdp * (cd * dy + cb * dx);
-                v[2] = h * dx * dx;
-                v[3] = h * dx * dy;
-                v[4] = h * dy * dy;
+                v[0] = qx;
+                v[1] = qy;
+                v[2] = qx * dx;
+                v[3] = qx * dy;
+                v[4] = qy * dy;
                 v[5] = G * dLdw;
                 v[6] = alpha * gr;
                 v[7] = alpha * gg;
                 v[8] = alpha * gb;
                 v[9] = alpha * gz;
                 A += alpha;
-                done = done || (1.0f - A) < t_eps;
-                const float red = wave_reduce_scatter10(v, (lane & 1) != 0, (lane & 2) != 0);
-                // lanes 48.. hold the totals; lane 54 (a duplicate) carries the "written" flag instead
-                if (red_slot >= 0) ((float*)&acc_all[wave][c0 + kk][0])[red_slot] = (lane == 54) ? 1.0f : red;
+                T = 1.0f - A;
+                P = T < t_eps ? P_STOPPED : P;
+                const float red = wave_reduce_scatter10(v);
+                if (red_slot >= 0) ((float*)&acc_all[wave][c0 + kk][0])[red_slot] = (lane == 36) ? 1.0f : red;
             }
         }
         __syncthreads();
-        // flush: 16 lanes per pair, lanes 0..9 carry the row summed over the waves that hit it
+        // flush: 16 lanes per pair, lanes 0..9 carry the row summed over the waves that hit it.
+        // Floats 0..4 are the moments (sum q dx, q dy, q dx^2, q dx dy, q dy^2); the gradient row is
+        //   d mean = (a Sx + b Sy, d Sy + b Sx),  d conic = -0.5 (Sxx, Sxy, Syy).
         const int sub = tid & 15;
 #pragma unroll 2
         for (int r = 0; r < BATCH / 16; ++r) {
             const int j = r * 16 + (tid >> 4);
+            float sum = 0.0f;
+            bool any = false;
             if (j < n && sub < 10) {
-                float sum = 0.0f;
-                bool any = false;
 #pragma unroll
                 for (int w2 = 0; w2 < NW; ++w2) {
                     const uint32_t p = posmap_all[w2][j];
@@ -338,7 +367,19 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                         if (a[10] != 0.0f) { sum += a[sub]; any = true; }
                     }
                 }
-                if (any) atomicAdd(grad_rows + (size_t)sid[j] * GS_GRAD_ROW + sub, sum);
+            }
+            const float other = __shfl_xor(sum, 1);
+            if (any) {
+                float outv = sum;
+                if (sub < 2) {
+                    const float* rq = (const float*)&sq[3 * j];
+                    const float ca = rq[2] * (-2.0f / GS_LOG2E), cb = rq[3] * (-1.0f / GS_LOG2E),
+                                cd = rq[4] * (-2.0f / GS_LOG2E);
+                    outv = (sub == 0 ? ca : cd) * sum + cb * other;
+                } else if (sub < 5) {
+                    outv = -0.5f * sum;
+                }
+                atomicAdd(grad_rows + (size_t)sid[j] * GS_GRAD_ROW + sub, outv);
             }
         }
     }

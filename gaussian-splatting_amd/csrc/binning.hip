@@ -1,13 +1,15 @@
-// Binning stage: duplicate every drawn Gaussian once per 16x16 tile its box overlaps, with a
-// 64-bit key = tile_id << 32 | depth_key (ascending key order == tile-major, far-to-near), and
-// find each tile's [start,end) in the sorted list.
+// Binning stage: duplicate every drawn Gaussian once per 16x16 tile its box overlaps, keyed by
+// the tile id, and find each tile's [start,end) in the tile-sorted list.
 //
 // The reference has no binning (it splats each Gaussian over its box in one global far-to-near
-// order, gaussian_renderer/__init__.py:151-159, :366); the keys reproduce that order inside every
-// tile: descending depth, ties by ascending Gaussian index (the sort is stable and pairs are
-// emitted in index order).  Bit-exact against oracle/gs_oracle.c::gso_duplicate_with_keys.
+// order, gaussian_renderer/__init__.py:151-159, :366).  Here that one global order is the
+// per-Gaussian depth sort (`order`, descending depth, ties by ascending Gaussian index: the sort
+// is stable); pairs are emitted in that order, so a STABLE sort on the tile id alone leaves every
+// tile's list far-to-near.  Bit-exact against oracle/gs_oracle.c (gso_duplicate_with_keys +
+// gso_sort_pairs on tile_id << 32 | depth_key give the same list).
 //
-// HBM-bound: 48 B record + 8 B (offset, count) read per drawn Gaussian, 12 B written per pair.
+// HBM-bound: 32 B of the record gathered + 12 B (id, offset, count) read per Gaussian, 8 B
+// written per pair.
 #include "gsplat_common.h"
 
 namespace {
@@ -16,58 +18,55 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int til
                                                                    const uint32_t* __restrict__ order,
                                                                    const float4* __restrict__ splat,
                                                                    const uint32_t* __restrict__ offsets,
-                                                                   const uint32_t* __restrict__ tiles_touched,
-                                                                   uint64_t* __restrict__ keys,
+                                                                   const uint32_t* __restrict__ tiles_in_order,
+                                                                   uint32_t* __restrict__ keys,
                                                                    uint32_t* __restrict__ vals) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
-    // with `order` (Gaussian ids far-to-near) lane r emits the Gaussian of depth rank r at
-    // offsets[r], so the emitted list is already sorted on the low 32 key bits
+    if (tiles_in_order[r] == 0) return;
+    // lane r emits the Gaussian of depth rank r at offsets[r]
     const int i = order ? (int)order[r] : r;
-    if (tiles_touched[i] == 0) return;
-    const float4 q1 = splat[3 * (size_t)i + 1];
-    const float4 q2 = splat[3 * (size_t)i + 2];
-    const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+    const uint32_t rx = __float_as_uint(splat[3 * (size_t)i + 1].w), ry = __float_as_uint(splat[3 * (size_t)i + 2].w);
     const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
     const int tx0 = xmin / GS_TILE, tx1 = (xmax - 1) / GS_TILE + 1;
     int ty0 = ymin / GS_TILE, ty1 = (ymax - 1) / GS_TILE + 1;
     ty0 = ty0 > row_b ? ty0 : row_b;
     ty1 = ty1 < row_e ? ty1 : row_e;
-    const uint32_t dk = gs_depth_key_desc(q1.z);
     size_t o = offsets[r];
     for (int ty = ty0; ty < ty1; ++ty)
         for (int tx = tx0; tx < tx1; ++tx) {
-            keys[o] = ((uint64_t)(uint32_t)(ty * tiles_x + tx) << 32) | dk;
+            keys[o] = (uint32_t)(ty * tiles_x + tx);
             vals[o] = (uint32_t)i;
             ++o;
         }
 }
 
-__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, const uint32_t* __restrict__ keys,
                                                                     uint32_t* __restrict__ ranges) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[2 * (size_t)t] = (uint32_t)i;
-    if (i == D - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[2 * (size_t)t + 1] = (uint32_t)(i + 1);
+    const uint32_t t = keys[i];
+    if (i == 0 || keys[i - 1] != t) ranges[2 * (size_t)t] = (uint32_t)i;
+    if (i == D - 1 || keys[i + 1] != t) ranges[2 * (size_t)t + 1] = (uint32_t)(i + 1);
 }
 
 }  // namespace
 
 extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
-                                      const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
+                                      const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals,
                                       int tile_row_begin, int tile_row_end, void* stream_) {
     GS_REQUIRE(N >= 0 && W > 0, "bad arguments");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(splat && offsets && tiles_touched && keys && vals, "null buffer");
+    GS_REQUIRE(splat && offsets && tiles_in_order && keys && vals, "null buffer");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream_, N,
-                       tiles_x, tile_row_begin, tile_row_end, order, (const float4*)splat, offsets, tiles_touched, keys, vals);
+                       tiles_x, tile_row_begin, tile_row_end, order, (const float4*)splat, offsets, tiles_in_order, keys,
+                       vals);
     GS_CHECK_LAUNCH("duplicate_with_keys");
     return GS_OK;
 }
 
-extern "C" int gs_identify_tile_ranges(long long D, int num_tiles, const uint64_t* keys, uint32_t* ranges,
+extern "C" int gs_identify_tile_ranges(long long D, int num_tiles, const uint32_t* keys, uint32_t* ranges,
                                        void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GS_REQUIRE(D >= 0 && num_tiles > 0 && ranges, "bad arguments");

@@ -39,8 +39,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wa
     return base + incl - v;
 }
 
+// with `gather`: sums in[gather[i]] and leaves the gathered values in gathered[i] for the final pass
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in,
-                                                                    const uint32_t* __restrict__ gather, long long n,
+                                                                    const uint32_t* __restrict__ gather,
+                                                                    uint32_t* __restrict__ gathered, long long n,
                                                                     uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
     const long long base = (long long)blockIdx.x * SCAN_TILE;
@@ -48,7 +50,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         const long long idx = base + (long long)j * SCAN_THREADS + threadIdx.x;  // coalesced
-        if (idx < n) s += gather ? in[gather[idx]] : in[idx];
+        if (idx < n) {
+            uint32_t v;
+            if (gather) {
+                v = in[gather[idx]];
+                gathered[idx] = v;
+            } else {
+                v = in[idx];
+            }
+            s += v;
+        }
     }
     uint32_t total;
     block_excl_scan(s, lds_wave, total);
@@ -72,8 +83,7 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
 }
 
 // in == out is allowed (each lane reads its 16 elements before it writes them)
-__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t* in,
-                                                                   const uint32_t* __restrict__ gather, long long n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t* in, long long n,
                                                                    const uint32_t* __restrict__ block_sums,
                                                                    uint32_t* out) {
     __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
@@ -81,10 +91,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const uint32_t
     const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
-    if (gather) {   // out[i] = exclusive scan of in[gather[i]] (scan in sorted order)
-#pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; ++j) v[j] = (base + j < n) ? in[gather[base + j]] : 0u;
-    } else if (base + SCAN_ITEMS <= n) {
+    if (base + SCAN_ITEMS <= n) {
         const uint4* p = reinterpret_cast<const uint4*>(in + base);
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS / 4; ++j) {
@@ -127,19 +134,21 @@ size_t gs_scan_ws_bytes(long long n) {
 }
 
 int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32_t* total_out,
-                          const uint32_t* gather, void* ws, hipStream_t stream) {
+                          const uint32_t* gather, uint32_t* gathered, void* ws, hipStream_t stream) {
     if (n <= 0) {
         if (total_out) GS_CHECK_HIP(hipMemsetAsync(total_out, 0, sizeof(uint32_t), stream));
         return GS_OK;
     }
     GS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "scan buffers must be 16-byte aligned");
+    GS_REQUIRE(!gather || (gathered && ((uintptr_t)gathered & 15) == 0), "gathered scan needs a 16-byte aligned buffer");
     const int nblocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     uint32_t* sums = (uint32_t*)ws;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, gather, n, sums);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, gather, gathered, n, sums);
     GS_CHECK_LAUNCH("scan_reduce");
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks, total_out);
     GS_CHECK_LAUNCH("scan_sums");
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, in, gather, n, sums, out);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, gather ? gathered : in, n, sums,
+                       out);
     GS_CHECK_LAUNCH("scan_final");
     return GS_OK;
 }
@@ -148,12 +157,14 @@ int gs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, long long n, uint32
 // when host_total is given, synchronously to the host.
 extern "C" size_t gs_scan_workspace_bytes(long long n) { return gs_scan_ws_bytes(n); }
 
-extern "C" int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
-                             uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream_) {
+extern "C" int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order,
+                             uint32_t* tiles_in_order, uint32_t* offsets, uint32_t* total_dev, void* workspace,
+                             uint32_t* host_total, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GS_REQUIRE(N >= 0 && total_dev, "bad arguments");
     GS_REQUIRE(N == 0 || (tiles_touched && offsets && workspace), "null buffer");
-    int rc = gs_exclusive_scan_u32(tiles_touched, offsets, N, total_dev, order, workspace, stream);
+    GS_REQUIRE(N == 0 || !order || tiles_in_order, "tiles_in_order is required with order");
+    int rc = gs_exclusive_scan_u32(tiles_touched, offsets, N, total_dev, order, tiles_in_order, workspace, stream);
     if (rc) return rc;
     if (host_total) {
         GS_CHECK_HIP(hipMemcpyAsync(host_total, total_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -64,7 +64,7 @@ class BinningState(NamedTuple):
     order: torch.Tensor          # (N,) Gaussian ids far-to-near (culled ones last), stable in the index
     offsets: torch.Tensor        # (N,) exclusive scan of tiles_touched[order]
     num_pairs: int               # D
-    keys: torch.Tensor           # (D,) sorted 64-bit keys (int64 storage)
+    keys: torch.Tensor           # (D,) tile id per sorted pair (int32 storage)
     point_list: torch.Tensor     # (D,) Gaussian index per sorted pair (int32 storage)
     ranges: torch.Tensor         # (tiles,2) i32
 
@@ -145,33 +145,34 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     ws_bytes = lib.gs_sort_workspace_bytes(N)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
     with _stage("sort_depth"):
-        _lib.check(lib.gs_sort_pairs32(N, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
-                                       _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs32")
+        _lib.check(lib.gs_sort_pairs(N, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
+                                       _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     order = ids[1 if in_b.value else 0][:N]
     offsets = torch.empty((N,), **i32)
+    tiles_in_order = torch.empty((N,), **i32)
     total = torch.empty((1,), **i32)
     scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
     host_total = C.c_uint32(0)
     with _stage("scan_tiles"):
-        _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(offsets), _ptr(total),
+        _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(tiles_in_order), _ptr(offsets), _ptr(total),
                                      _ptr(scan_ws), C.byref(host_total), st), "gs_scan_tiles")
     D = int(host_total.value)
     tiles_x, tiles_y = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     ntiles = tiles_x * tiles_y
-    keys_a = torch.empty((max(D, 1),), dtype=torch.int64, device=dev)
-    keys_b = torch.empty((max(D, 1),), dtype=torch.int64, device=dev)
+    keys_a = torch.empty((max(D, 1),), **i32)
+    keys_b = torch.empty((max(D, 1),), **i32)
     vals_a = torch.empty((max(D, 1),), **i32)
     vals_b = torch.empty((max(D, 1),), **i32)
     with _stage("duplicate_with_keys"):
-        _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(order), _ptr(offsets), _ptr(tiles_touched),
+        _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(order), _ptr(offsets), _ptr(tiles_in_order),
                                               _ptr(keys_a), _ptr(vals_a), row_b, row_e, st),
                    "gs_duplicate_with_keys")
-    # pairs were emitted far-to-near, so only the tile bits are left to sort (stable)
-    bits = 32 + max(1, (ntiles - 1).bit_length())
+    # pairs were emitted far-to-near, so only the tile id is left to sort (stable)
+    bits = max(1, (ntiles - 1).bit_length())
     ws_bytes = lib.gs_sort_workspace_bytes(D)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
     with _stage("sort_pairs"):
-        _lib.check(lib.gs_sort_pairs(D, 32, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
+        _lib.check(lib.gs_sort_pairs(D, 0, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
                                      _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     keys, point_list = (keys_b, vals_b) if in_b.value else (keys_a, vals_a)
     ranges = torch.empty((ntiles, 2), **i32)

@@ -55,8 +55,8 @@ int gs_grad_row_floats(void);    /* 16: floats per per-Gaussian gradient row (se
  * Outputs: splat (N x 12 floats, 48-byte records, layout in csrc/gsplat_common.h; rows of culled
  * Gaussians are not written), radii (N) int32 = ceil(3 sigma_max) or 0 when not drawn,
  * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.  depth_keys / ids (N each,
- * both or neither NULL): input of the per-Gaussian depth sort, depth_keys[i] = key(depth) as in
- * gs_duplicate_with_keys (0xFFFFFFFF for Gaussians that are not drawn, so they sort last), ids[i] = i.
+ * both or neither NULL): input of the per-Gaussian depth sort, depth_keys[i] = 32-bit key whose
+ * ascending order is descending depth (0xFFFFFFFF for Gaussians that are not drawn, so they sort last), ids[i] = i.
  */
 int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                       const float* projmatrix, const float* campos, const float* means3D,
@@ -66,35 +66,35 @@ int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* vi
                       uint32_t* ids, int tile_row_begin, int tile_row_end, void* stream);
 
 /*
- * Binning stage.  No counterpart in the reference (it has one global far-to-near order,
- * torch.argsort at :153, and loops over Gaussians :366); the keys reproduce that order per tile.
+ * Binning stage.  The reference has one global far-to-near order (torch.argsort at
+ * gaussian_renderer/__init__.py:153) and loops over Gaussians (:366).  Here that order is the
+ * per-Gaussian depth sort: gs_sort_pairs on (depth_keys, ids), all 32 bits -> `order` = Gaussian ids
+ * by descending depth, ties by ascending index, Gaussians that are not drawn last.  Pairs (tile id,
+ * Gaussian id) are emitted in that order and then STABLY sorted on the tile id alone, which leaves
+ * every tile's list far-to-near.
  */
 size_t gs_scan_workspace_bytes(long long N);
-/* offsets[r] = exclusive scan of tiles_touched[order[r]] (order == NULL: of tiles_touched[r]);
- * *total_dev = D; host_total (host pointer, may be NULL) receives D after a stream synchronise. */
-int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* offsets,
-                  uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream);
-/* keys[o] = tile_id << 32 | key(depth) (ascending key = descending depth), vals[o] = Gaussian
- * index i = order[r] (order == NULL: i = r), for o in [offsets[r], offsets[r] + tiles_touched[i]),
- * tiles in row-major order.  With `order` = the Gaussian ids sorted by depth key (gs_sort_pairs32)
- * the emitted list is already sorted on the low 32 key bits. */
+/* offsets[r] = exclusive scan of tiles_touched[order[r]] and tiles_in_order[r] = tiles_touched[order[r]]
+ * (order == NULL: plain exclusive scan of tiles_touched, tiles_in_order unused); *total_dev = D;
+ * host_total (host pointer, may be NULL) receives D after a stream synchronise. */
+int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* tiles_in_order,
+                  uint32_t* offsets, uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream);
+/* keys[o] = tile id (row-major), vals[o] = Gaussian index i = order[r] (order == NULL: i = r), for
+ * o in [offsets[r], offsets[r] + tiles_in_order[r]), tiles of one Gaussian in row-major order.
+ * With order == NULL pass tiles_touched as tiles_in_order. */
 int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
-                           const uint32_t* tiles_touched, uint64_t* keys, uint32_t* vals,
+                           const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals,
                            int tile_row_begin, int tile_row_end, void* stream);
 size_t gs_sort_workspace_bytes(long long D);
-/* Stable LSD radix sort on key bits [bit_begin, bit_end) (8 per pass).  Input in (keys_a, vals_a);
- * *result_in_b (host int) = 1 when the sorted pairs ended in (keys_b, vals_b).  The frame pipeline
- * sorts the N (depth key, id) pairs on all 32 bits with gs_sort_pairs32 -- the reference's one
- * global far-to-near order, torch.argsort at :153 -- and the D (tile|depth, id) pairs on the tile
- * bits [32, 32 + tile_bits) only. */
-int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint64_t* keys_a, uint32_t* vals_a,
-                  uint64_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
+/* Stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits [bit_begin, bit_end), 8 per
+ * pass, at most 4 passes.  Input in (keys_a, vals_a); *result_in_b (host int) = 1 when the sorted
+ * pairs ended in (keys_b, vals_b).  Used twice per frame: depth keys of the N Gaussians (bits 0..32)
+ * and tile ids of the D pairs (bits 0..tile_bits). */
+int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint32_t* keys_a, uint32_t* vals_a,
+                  uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
                   int* result_in_b, void* stream);
-int gs_sort_pairs32(long long D, int bit_begin, int bit_end, uint32_t* keys_a, uint32_t* vals_a,
-                    uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
-                    int* result_in_b, void* stream);
 /* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty). */
-int gs_identify_tile_ranges(long long D, int num_tiles, const uint64_t* keys, uint32_t* ranges,
+int gs_identify_tile_ranges(long long D, int num_tiles, const uint32_t* keys, uint32_t* ranges,
                             void* stream);
 
 /*

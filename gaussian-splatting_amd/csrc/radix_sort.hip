@@ -8,10 +8,9 @@
 // order, so a stable sort on the tile id alone leaves every tile's list far-to-near.
 //
 // Two launches per pass (no separate scan kernels):
-//   1. histogram: each workgroup counts the digits of its 4096-key tile (wave64 ballot "match":
-//      one LDS add per distinct digit per wave, so skewed digits cost the same as random ones),
-//      stores its 256 counts (blk table) and adds them to the counts of its group of 32
-//      workgroups (grp table, low-contention global atomics);
+//   1. histogram: each workgroup counts the digits of its 4096-key tile with LDS adds (one add per
+//      wave when all its 64 keys share the digit), stores its 256 counts (blk table) and adds them
+//      to the counts of its group of 32 workgroups (grp table, low-contention global atomics);
 //   2. scatter: lane d of every workgroup sums the grp rows before its group, the blk rows before
 //      it inside its group, and all grp rows (digit totals -> block scan) to get the global base of
 //      its (digit, workgroup) run -- ~(nblocks/32 + 32) independent coalesced 1 KB reads from L2,
@@ -54,16 +53,30 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
                                                                  uint32_t* __restrict__ grp) {
     __shared__ uint32_t hist[RS_RADIX];
     hist[threadIdx.x] = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long base = (long long)blockIdx.x * RS_TILE + (long long)wave * 64 * RS_ITEMS;
-#pragma unroll 4
+    uint32_t key[RS_ITEMS];
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {   // all loads in flight before the first LDS add
+        const long long idx = base + it * 64 + lane;
+        key[it] = idx < D ? keys[idx] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
         const long long idx = base + it * 64 + lane;
         const bool valid = idx < D;
-        const uint32_t d = valid ? (keys[idx] >> shift) & mask : 0u;
-        const uint64_t peers = match_digit(d, valid);
-        if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
+        const uint32_t d = (key[it] >> shift) & mask;
+        // LDS adds cost one cycle per lane on the same address: a wave whose 64 keys share the digit
+        // (high bytes of depth keys, tile ids of a sorted list) adds once; anything else goes to
+        // the LDS atomic unit directly (cheaper than ranking the lanes with ballots)
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__all(d == d0 || !valid)) {
+            const uint64_t m = __ballot(valid);
+            if (lane == 0 && m) atomicAdd(&hist[d0], (uint32_t)__popcll(m));
+        } else if (valid) {
+            atomicAdd(&hist[d], 1u);
+        }
     }
     __syncthreads();
     const uint32_t c = hist[threadIdx.x];

@@ -41,6 +41,7 @@
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct Rec { f4 q0, q1, q2; };
 
@@ -68,6 +69,12 @@ __device__ __forceinline__ void to_lds_form(f4& p0, f4& p1, f4& p2) {
     p1.x *= -0.5f * GS_LOG2E;
     p1.w = __uint_as_float((rx & 0xFFFFu) | (ry << 16));
     p2.w = __uint_as_float(((rx >> 16) - 1u) | (((ry >> 16) - 1u) << 16));
+}
+
+// log2 e * power = (A' dx + B' dy) dx + (C' dy) dy : mul, fma, mul, mul, fma
+__device__ __forceinline__ float gauss_power2(const Rec& rec, float dx, float dy) {
+    const float t = __builtin_fmaf(rec.q0.w, dy, rec.q0.z * dx);
+    return __builtin_fmaf(rec.q1.x * dy, dy, t * dx);
 }
 
 // packed pixel inside the packed inclusive box?  (2 x v_pk_{max,min}_u16 + v_cmp)
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
                 const Rec rec = load_rec(sq, __builtin_amdgcn_readlane(jv, kk));
                 const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
                 const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
-                const float power2 = (rec.q0.z * dx + rec.q0.w * dy) * dx + (rec.q1.x * dy) * dy;
+                const float power2 = gauss_power2(rec, dx, dy);
                 const float w = __builtin_amdgcn_exp2f(power2) * rec.q1.y;
                 const float alpha = act ? w * T : 0.0f;
                 Cr += alpha * rec.q2.x;
@@ -290,7 +297,8 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         total = (gr * aux_rgb[p] + gg * aux_rgb[HW + p] + gb * aux_rgb[2 * HW + p]) + gz * out_depth[p] +
                 ga * out_alpha[p];
     }
-    float A = 0.f, T = 1.f, prefix = 0.f;
+    float A = 0.f, T = 1.f, rem = total;
+    const f2 g_rg = {gr, gg}, g_bz = {gb, gz};
     uint32_t P = c.inside ? ((uint32_t)c.px | (uint32_t)c.py << 16) : P_STOPPED;
     // which float of the 12-float slot this lane stores after wave_reduce_scatter10 (-1: none):
     // value v_k = row float k; lane 36 (a duplicate of v4) carries the "written" flag, float 10
@@ -319,28 +327,31 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                 const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
                 if (!__any(act)) continue;   // slot keeps flag 0
                 const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
-                const float power2 = (rec.q0.z * dx + rec.q0.w * dy) * dx + (rec.q1.x * dy) * dy;
+                const float power2 = gauss_power2(rec, dx, dy);
                 const float G = act ? __builtin_amdgcn_exp2f(power2) : 0.0f;  // inactive lanes: every sum gets 0
                 const float w = G * rec.q1.y;
                 const float alpha = w * T;
-                const float u = (rec.q2.x * gr + rec.q2.y * gg + rec.q2.z * gb) + rec.q1.z * gz + ga;
-                prefix += u * alpha;
-                const float suffix = total - prefix;
+                const float u = __builtin_fmaf(rec.q2.x, g_rg.x, __builtin_fmaf(rec.q2.y, g_rg.y,
+                                __builtin_fmaf(rec.q2.z, g_bz.x, __builtin_fmaf(rec.q1.z, g_bz.y, ga))));
+                rem = __builtin_fmaf(-u, alpha, rem);      // total - sum_{j<=i} u_j alpha_j
                 const float inv = __builtin_amdgcn_rcpf(fmaxf(1.0f - w, 1e-6f));
-                const float dLdw = T * u - suffix * inv;
+                const float dLdw = T * u - rem * inv;
                 const float q = w * dLdw;          // dL/dpower
-                const float qx = q * dx, qy = q * dy;
+                const f2 dxy = {dx, dy};
+                const f2 qxy = q * dxy;            // v_pk_mul_f32
+                const f2 qxd = qxy.x * dxy;
+                const f2 c_rg = alpha * g_rg, c_bz = alpha * g_bz;
                 float v[10];
-                v[0] = qx;
-                v[1] = qy;
-                v[2] = qx * dx;
-                v[3] = qx * dy;
-                v[4] = qy * dy;
+                v[0] = qxy.x;
+                v[1] = qxy.y;
+                v[2] = qxd.x;
+                v[3] = qxd.y;
+                v[4] = qxy.y * dy;
                 v[5] = G * dLdw;
-                v[6] = alpha * gr;
-                v[7] = alpha * gg;
-                v[8] = alpha * gb;
-                v[9] = alpha * gz;
+                v[6] = c_rg.x;
+                v[7] = c_rg.y;
+                v[8] = c_bz.x;
+                v[9] = c_bz.y;
                 A += alpha;
                 T = 1.0f - A;
                 P = T < t_eps ? P_STOPPED : P;

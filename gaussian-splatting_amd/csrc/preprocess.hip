@@ -319,8 +319,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         if (colors_precomp) {
             gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
         } else if (shs) {
-            float sh[NB * 3 + 3], b[NB], bg[NB][3];
-            load_sh<NB, VEC4>(shs, i, K, sh);
+            float b[NB], bg[NB][3];
             const float vx = px - campos[0], vy = py - campos[1], vz = pz - campos[2];
             const float n = sqrtf(vx * vx + vy * vy + vz * vz);
             const float ne = n + 1e-7f;
@@ -330,30 +329,62 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             const float dcol[3] = {d_r, d_g, d_bl};
             float gcl[3];
             float ddir[3] = {0.f, 0.f, 0.f};
+            // one streaming pass over the coefficients (each loaded value is consumed at once, so the
+            // 48 floats never sit in registers together): colour v[c] = sum_k b_k sh_kc and
+            // Wm[a][c] = sum_k (d b_k / d dir_a) sh_kc; the clamp mask is applied afterwards
+            float vcol[3] = {0.f, 0.f, 0.f};
+            float Wm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            {
+                const float* p = shs + (size_t)i * K * 3;
+                constexpr int NF = NB * 3;
+                constexpr int NV = VEC4 ? (NF + 3) / 4 : 0;
+                const float4* p4 = reinterpret_cast<const float4*>(p);
+                float4 t4[NV > 0 ? NV : 1];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v = 0.0f;
+                for (int v = 0; v < NV; ++v) t4[v] = p4[v];
 #pragma unroll
-                for (int k = 0; k < NB; ++k) v += b[k] * sh[3 * k + c];
-                v += 0.5f;
-                gcl[c] = (v >= 0.0f && v <= 1.0f) ? dcol[c] : 0.0f;
-            }
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float sg = sh[3 * k + c] * gcl[c];
-                    ddir[0] += bg[k][0] * sg;
-                    ddir[1] += bg[k][1] * sg;
-                    ddir[2] += bg[k][2] * sg;
+                for (int f = 0; f < NF; ++f) {
+                    float val;
+                    if (VEC4) {
+                        const float4 t = t4[f / 4];
+                        val = (f % 4 == 0) ? t.x : (f % 4 == 1) ? t.y : (f % 4 == 2) ? t.z : t.w;
+                    } else {
+                        val = p[f];
+                    }
+                    const int k = f / 3, c = f % 3;
+                    vcol[c] += b[k] * val;
+                    Wm[0][c] += bg[k][0] * val;
+                    Wm[1][c] += bg[k][1] * val;
+                    Wm[2][c] += bg[k][2] * val;
                 }
             }
-            if (gsh_out) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    gsh_out[3 * k + 0] = b[k] * gcl[0];
-                    gsh_out[3 * k + 1] = b[k] * gcl[1];
-                    gsh_out[3 * k + 2] = b[k] * gcl[2];
+            for (int c = 0; c < 3; ++c) {
+                const float v = vcol[c] + 0.5f;
+                gcl[c] = (v >= 0.0f && v <= 1.0f) ? dcol[c] : 0.0f;
+#pragma unroll
+                for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
+            }
+            if (gsh_out) {
+                if (VEC4) {   // 16-byte stores: a quarter of the partial-line write requests
+                    constexpr int NV = (NB * 3) / 4;      // whole float4s; the 0..3 floats left go scalar
+                    float4* o4 = reinterpret_cast<float4*>(gsh_out);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = b[(4 * v + e) / 3] * gcl[(4 * v + e) % 3];
+                        o4[v] = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+#pragma unroll
+                    for (int f = 4 * NV; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        gsh_out[3 * k + 0] = b[k] * gcl[0];
+                        gsh_out[3 * k + 1] = b[k] * gcl[1];
+                        gsh_out[3 * k + 2] = b[k] * gcl[2];
+                    }
                 }
                 sh_written = NB * 3;
             }
@@ -464,8 +495,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     }
     if (g_opac) g_opac[i] = gop;
     if (g_colors) { g_colors[3 * (size_t)i] = gcol[0]; g_colors[3 * (size_t)i + 1] = gcol[1]; g_colors[3 * (size_t)i + 2] = gcol[2]; }
-    if (gsh_out)
-        for (int k = sh_written; k < K * 3; ++k) gsh_out[k] = 0.0f;
+    if (gsh_out) {
+        int k = sh_written;
+        if (VEC4 && (k & 3) == 0) {
+            float4* o4 = reinterpret_cast<float4*>(gsh_out);
+            for (; k + 4 <= K * 3; k += 4) o4[k >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (; k < K * 3; ++k) gsh_out[k] = 0.0f;
+    }
 }
 
 template <int DEG>
@@ -563,7 +600,7 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
     GS_REQUIRE(!g_rotations || ((uintptr_t)g_rotations & 15) == 0, "g_rotations must be 16-byte aligned");
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0);
+    const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0) && (((uintptr_t)g_shs & 15) == 0);
     const int deg = shs ? sh_degree : 0;
     const float4* rows = (const float4*)grad_rows;
     switch (deg) {

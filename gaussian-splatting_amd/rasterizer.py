@@ -31,9 +31,10 @@ TILE = 16
 GRAD_ROW = 16
 
 # Per-pixel stop threshold on the transmittance 1 - alpha_acc (see csrc/render.hip).  0.0 disables
-# it (bit-for-bit the reference's "no early termination"); what is dropped at the default is at
-# most 1e-6 * (sum of remaining alpha*colour), far below the stated 1e-4 image tolerance.
-DEFAULT_T_EPS = 1e-6
+# it (the reference's "no early termination"); what a pixel drops at the default is at most
+# 1e-5 * max|colour| (1e-5 * max depth for the depth map), a tenth of the stated 1e-4 image / 1e-3
+# depth tolerance; gradients lose terms of the same relative size.
+DEFAULT_T_EPS = 1e-5
 
 
 class GaussianRasterizationSettings:

@@ -57,7 +57,7 @@ def _run_hip(dgr, g, t_eps, G=None):
     return image, radii, depth, alpha, inp, means2D
 
 
-@pytest.mark.parametrize("t_eps", [0.0, 1e-6])
+@pytest.mark.parametrize("t_eps", [0.0, 1e-5])  # exact, and the library default
 @pytest.mark.parametrize("name", NAMES)
 def test_golden_forward_backward(dgr, name, t_eps):
     g = load_golden(name)
@@ -193,10 +193,14 @@ def test_early_stop_is_within_tolerance(dgr):
         torch.cuda.synchronize()
         res.append((image.detach().cpu().numpy(), depth.detach().cpu().numpy(),
                     {k: v.grad.cpu().numpy() for k, v in inp.items()}))
-    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-5
-    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-4
+    # a stopped pixel drops at most t_eps * max|colour| (colour <= 1) resp. t_eps * max depth (z < 10.5)
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1.05 * dgr.DEFAULT_T_EPS
+    assert np.abs(res[0][1] - res[1][1]).max() <= 10.5 * dgr.DEFAULT_T_EPS
     for k in res[0][2]:
-        check_grad("early_stop:d_" + k, res[1][2][k], res[0][2][k], rel=1e-4)
+        # the backward is the exact gradient of the truncated forward; against the untruncated one it
+        # differs by d(dropped tail)/d theta <= t_eps |u| / (1 - w_i) per pixel.  Measured on this
+        # scene: 1.4e-4 * max|grad| (opacities); budget here: half the stated 1e-3 tolerance.
+        check_grad("early_stop:d_" + k, res[1][2][k], res[0][2][k], rel=5e-4)
 
 
 def test_errors_and_edge_shapes(dgr):

@@ -279,7 +279,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     o[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(ry));
 }
 
-template <int DEG, bool VEC4>
+// MODE 0: scalar SH access; 1: 16-byte SH loads/stores per lane (rows 16-byte aligned);
+// 2: like 1 but staged through LDS so that HBM sees the wave's 64 consecutive SH rows as one
+//    contiguous stream of full 16-byte-per-lane requests (rows of at most 48 floats).
+constexpr int BWD_STAGE_MAX_ROW = 48;
+constexpr int BWD_STAGE_STRIDE = BWD_STAGE_MAX_ROW + 1;   // odd stride: per-lane rows hit all banks
+
+template <int DEG, int MODE>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, const float* __restrict__ means3D,
@@ -290,9 +296,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float* __restrict__ g_means2D, float* __restrict__ g_scales, float* __restrict__ g_rots,
     float* __restrict__ g_cov6, float* __restrict__ g_opac, float* __restrict__ g_shs,
     float* __restrict__ g_colors) {
+    constexpr bool VEC4 = MODE >= 1;
+    constexpr bool STAGE = MODE == 2;
+    __shared__ float stage_all[STAGE ? 4 * 64 * BWD_STAGE_STRIDE : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const bool drawn = radii[i] > 0;
+    const bool in_range = i < N;
+    if (!STAGE && !in_range) return;
+    const bool drawn = in_range && radii[i] > 0;
     float gm[3] = {0.f, 0.f, 0.f};
     float gm2[2] = {0.f, 0.f};
     float gs[3] = {0.f, 0.f, 0.f};
@@ -301,8 +311,29 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float gop = 0.f;
     float gcol[3] = {0.f, 0.f, 0.f};
     constexpr int NB = (DEG + 1) * (DEG + 1);
-    float* gsh_out = g_shs ? g_shs + (size_t)i * K * 3 : nullptr;
+    float* gsh_out = (g_shs && in_range) ? g_shs + (size_t)i * K * 3 : nullptr;
     int sh_written = 0;
+    // ---- staged SH rows of this wave's 64 Gaussians
+    const int lane = threadIdx.x & 63;
+    float* st_wave = stage_all + (STAGE ? (threadIdx.x >> 6) * 64 * BWD_STAGE_STRIDE : 0);
+    float* st_row = st_wave + (STAGE ? lane * BWD_STAGE_STRIDE : 0);
+    const int RL = 3 * K;
+    const int i0 = i - lane;                      // first Gaussian of this wave
+    const int nq = STAGE && i0 < N ? ((N - i0 < 64 ? N - i0 : 64) * RL) / 4 : 0;   // float4s in the chunk
+    if (STAGE && shs) {
+        const uint64_t dmask = __ballot(drawn);
+        const float4* p4 = reinterpret_cast<const float4*>(shs + (size_t)i0 * RL);
+        for (int m = lane; m < nq; m += 64) {
+            const unsigned f = 4u * (unsigned)m, gi = f / (unsigned)RL, off = f - gi * (unsigned)RL;
+            if ((dmask >> gi) & 1ull) {
+                const float4 t = p4[m];
+                float* d = st_wave + gi * BWD_STAGE_STRIDE + off;
+                d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     if (drawn) {
         Geom g;
         project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
@@ -337,7 +368,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             {
                 const float* p = shs + (size_t)i * K * 3;
                 constexpr int NF = NB * 3;
-                constexpr int NV = VEC4 ? (NF + 3) / 4 : 0;
+                constexpr int NV = (VEC4 && !STAGE) ? (NF + 3) / 4 : 0;
                 const float4* p4 = reinterpret_cast<const float4*>(p);
                 float4 t4[NV > 0 ? NV : 1];
 #pragma unroll
@@ -345,7 +376,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     float val;
-                    if (VEC4) {
+                    if (STAGE) {
+                        val = st_row[f];
+                    } else if (VEC4) {
                         const float4 t = t4[f / 4];
                         val = (f % 4 == 0) ? t.x : (f % 4 == 1) ? t.y : (f % 4 == 2) ? t.z : t.w;
                     } else {
@@ -365,7 +398,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
                 for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
             }
-            if (gsh_out) {
+            if (gsh_out && STAGE) {
+#pragma unroll
+                for (int f = 0; f < NB * 3; ++f) st_row[f] = b[f / 3] * gcl[f % 3];
+                sh_written = NB * 3;
+            } else if (gsh_out) {
                 if (VEC4) {   // 16-byte stores: a quarter of the partial-line write requests
                     constexpr int NV = (NB * 3) / 4;      // whole float4s; the 0..3 floats left go scalar
                     float4* o4 = reinterpret_cast<float4*>(gsh_out);
@@ -480,22 +517,39 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             gq[3] = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
         }
     }
-    if (g_means3D) { g_means3D[3 * (size_t)i] = gm[0]; g_means3D[3 * (size_t)i + 1] = gm[1]; g_means3D[3 * (size_t)i + 2] = gm[2]; }
-    if (g_means2D) {
-        // densification statistic: gradient w.r.t. the NDC-scaled screen mean (pixels * W/2, H/2)
-        g_means2D[3 * (size_t)i] = gm2[0] * 0.5f * (float)W;
-        g_means2D[3 * (size_t)i + 1] = gm2[1] * 0.5f * (float)H;
-        g_means2D[3 * (size_t)i + 2] = 0.0f;
-    }
-    if (g_scales) { g_scales[3 * (size_t)i] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2]; }
-    if (g_rots) *reinterpret_cast<float4*>(g_rots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
-    if (g_cov6) {
+    if (in_range) {
+        if (g_means3D) { g_means3D[3 * (size_t)i] = gm[0]; g_means3D[3 * (size_t)i + 1] = gm[1]; g_means3D[3 * (size_t)i + 2] = gm[2]; }
+        if (g_means2D) {
+            // densification statistic: gradient w.r.t. the NDC-scaled screen mean (pixels * W/2, H/2)
+            g_means2D[3 * (size_t)i] = gm2[0] * 0.5f * (float)W;
+            g_means2D[3 * (size_t)i + 1] = gm2[1] * 0.5f * (float)H;
+            g_means2D[3 * (size_t)i + 2] = 0.0f;
+        }
+        if (g_scales) { g_scales[3 * (size_t)i] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2]; }
+        if (g_rots) *reinterpret_cast<float4*>(g_rots + 4 * (size_t)i) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        if (g_cov6) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) g_cov6[6 * (size_t)i + k] = gc6[k];
+            for (int k = 0; k < 6; ++k) g_cov6[6 * (size_t)i + k] = gc6[k];
+        }
+        if (g_opac) g_opac[i] = gop;
+        if (g_colors) { g_colors[3 * (size_t)i] = gcol[0]; g_colors[3 * (size_t)i + 1] = gcol[1]; g_colors[3 * (size_t)i + 2] = gcol[2]; }
     }
-    if (g_opac) g_opac[i] = gop;
-    if (g_colors) { g_colors[3 * (size_t)i] = gcol[0]; g_colors[3 * (size_t)i + 1] = gcol[1]; g_colors[3 * (size_t)i + 2] = gcol[2]; }
-    if (gsh_out) {
+    if (STAGE) {
+        if (g_shs) {   // wave-uniform
+            if (in_range)
+                for (int k = sh_written; k < RL; ++k) st_row[k] = 0.0f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float4* q4 = reinterpret_cast<float4*>(g_shs + (size_t)i0 * RL);
+            for (int m = lane; m < nq; m += 64) {
+                const unsigned f = 4u * (unsigned)m, gi = f / (unsigned)RL, off = f - gi * (unsigned)RL;
+                const float* d = st_wave + gi * BWD_STAGE_STRIDE + off;
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v o = {d[0], d[1], d[2], d[3]};
+                __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(q4) + m);   // written once, read by the optimizer later
+            }
+        }
+    } else if (gsh_out) {
         int k = sh_written;
         if (VEC4 && (k & 3) == 0) {
             float4* o4 = reinterpret_cast<float4*>(gsh_out);
@@ -523,20 +577,20 @@ int launch_fwd(bool vec4, int N, int K, int H, int W, int row_b, int row_e, cons
 }
 
 template <int DEG>
-int launch_bwd(bool vec4, int N, int K, int H, int W, const float* view, const float* proj,
+int launch_bwd(int mode, int N, int K, int H, int W, const float* view, const float* proj,
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* shs, const float* colors, const int32_t* radii,
                const float4* rows, float* g_means3D, float* g_means2D, float* g_scales, float* g_rots,
                float* g_cov6, float* g_opac, float* g_shs, float* g_colors, hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
-    if (vec4)
-        hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, view, proj,
-                           campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D,
-                           g_means2D, g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors);
-    else
-        hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, view, proj,
-                           campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D,
-                           g_means2D, g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors);
+#define GS_LAUNCH_BWD(MODE)                                                                                      \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, MODE>), grid, block, 0, stream, N, K, H, W, view, proj, campos, \
+                       means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D, g_means2D, g_scales,    \
+                       g_rots, g_cov6, g_opac, g_shs, g_colors)
+    if (mode == 2) GS_LAUNCH_BWD(2);
+    else if (mode == 1) GS_LAUNCH_BWD(1);
+    else GS_LAUNCH_BWD(0);
+#undef GS_LAUNCH_BWD
     GS_CHECK_LAUNCH("preprocess_bwd");
     return GS_OK;
 }
@@ -601,12 +655,13 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0) && (((uintptr_t)g_shs & 15) == 0);
+    const int mode = vec4 ? (K * 3 <= BWD_STAGE_MAX_ROW ? 2 : 1) : 0;
     const int deg = shs ? sh_degree : 0;
     const float4* rows = (const float4*)grad_rows;
     switch (deg) {
-        case 0: return launch_bwd<0>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
-        case 1: return launch_bwd<1>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
-        case 2: return launch_bwd<2>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
-        default: return launch_bwd<3>(vec4, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
     }
 }

@@ -23,10 +23,10 @@ PROTOTYPES = {
     "gs_preprocess_bwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 19 + [_vp]),
     "gs_scan_workspace_bytes": (_sz, [_ll]),
     "gs_scan_tiles": (_i, [_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gs_duplicate_with_keys": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "gs_duplicate_with_keys": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "gs_sort_workspace_bytes": (_sz, [_ll]),
-    "gs_sort_pairs": (_i, [_ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "gs_identify_tile_ranges": (_i, [_ll, _i, _vp, _vp, _vp]),
+    "gs_sort_pairs": (_i, [_ll, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "gs_identify_tile_ranges": (_i, [_ll, _vp, _i, _vp, _vp, _vp]),
     "gs_render_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "gs_render_bwd": (_i, [_i, _i] + [_vp] * 10 + [_f, _i, _i, _vp]),
 }

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int til
                                                                    const uint32_t* __restrict__ offsets,
                                                                    const uint32_t* __restrict__ tiles_in_order,
                                                                    uint32_t* __restrict__ keys,
-                                                                   uint32_t* __restrict__ vals) {
+                                                                   uint32_t* __restrict__ vals, size_t capacity) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
     if (tiles_in_order[r] == 0) return;
@@ -35,14 +35,23 @@ __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int til
     size_t o = offsets[r];
     for (int ty = ty0; ty < ty1; ++ty)
         for (int tx = tx0; tx < tx1; ++tx) {
-            keys[o] = (uint32_t)(ty * tiles_x + tx);
-            vals[o] = (uint32_t)i;
+            if (o < capacity) {   // pairs beyond the caller's buffers are dropped (the caller checks D afterwards)
+                keys[o] = (uint32_t)(ty * tiles_x + tx);
+                vals[o] = (uint32_t)i;
+            }
             ++o;
         }
 }
 
-__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long cap,
+                                                                    const uint32_t* __restrict__ count_dev,
+                                                                    const uint32_t* __restrict__ keys,
                                                                     uint32_t* __restrict__ ranges) {
+    long long D = cap;
+    if (count_dev) {
+        const long long c = (long long)*count_dev;
+        D = c < cap ? c : cap;
+    }
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D) return;
     const uint32_t t = keys[i];
@@ -54,26 +63,27 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long D, 
 
 extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
                                       const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals,
-                                      int tile_row_begin, int tile_row_end, void* stream_) {
-    GS_REQUIRE(N >= 0 && W > 0, "bad arguments");
+                                      long long capacity, int tile_row_begin, int tile_row_end, void* stream_) {
+    GS_REQUIRE(N >= 0 && W > 0 && capacity >= 0, "bad arguments");
     if (N == 0) return GS_OK;
     GS_REQUIRE(splat && offsets && tiles_in_order && keys && vals, "null buffer");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream_, N,
                        tiles_x, tile_row_begin, tile_row_end, order, (const float4*)splat, offsets, tiles_in_order, keys,
-                       vals);
+                       vals, (size_t)capacity);
     GS_CHECK_LAUNCH("duplicate_with_keys");
     return GS_OK;
 }
 
-extern "C" int gs_identify_tile_ranges(long long D, int num_tiles, const uint32_t* keys, uint32_t* ranges,
-                                       void* stream_) {
+extern "C" int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, int num_tiles, const uint32_t* keys,
+                                       uint32_t* ranges, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GS_REQUIRE(D >= 0 && num_tiles > 0 && ranges, "bad arguments");
     GS_CHECK_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
     if (D == 0) return GS_OK;
     GS_REQUIRE(keys, "null keys");
-    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3(gs_div_up(D, 256)), dim3(256), 0, stream, D, keys, ranges);
+    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3(gs_div_up(D, 256)), dim3(256), 0, stream, D, count_dev, keys,
+                       ranges);
     GS_CHECK_LAUNCH("identify_tile_ranges");
     return GS_OK;
 }

@@ -47,11 +47,21 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return (1ull << lane) - 1ull;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, long long D,
+// count_dev != nullptr: the number of pairs lives on the device (no host read-back); `cap` sized the grid
+__device__ __forceinline__ long long actual_count(long long cap, const uint32_t* __restrict__ count_dev) {
+    if (!count_dev) return cap;
+    const long long c = (long long)*count_dev;
+    return c < cap ? c : cap;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, long long cap,
+                                                                 const uint32_t* __restrict__ count_dev,
                                                                  int shift, uint32_t mask,
                                                                  uint32_t* __restrict__ blk,
                                                                  uint32_t* __restrict__ grp) {
     __shared__ uint32_t hist[RS_RADIX];
+    const long long D = actual_count(cap, count_dev);
+    if ((long long)blockIdx.x * RS_TILE >= D) return;   // workgroup-uniform
     hist[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long base = (long long)blockIdx.x * RS_TILE + (long long)wave * 64 * RS_ITEMS;
@@ -86,8 +96,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
 
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, long long D, int shift, uint32_t mask, int ngroups, const uint32_t* __restrict__ blk,
-    const uint32_t* __restrict__ grp) {
+    uint32_t* __restrict__ vals_out, long long cap, const uint32_t* __restrict__ count_dev, int shift, uint32_t mask,
+    const uint32_t* __restrict__ blk, const uint32_t* __restrict__ grp) {
     __shared__ uint32_t skeys[RS_TILE];
     __shared__ uint32_t svals[RS_TILE];
     __shared__ uint32_t wave_cnt[RS_WAVES][RS_RADIX];
@@ -95,6 +105,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t gofs[RS_RADIX];
     __shared__ uint32_t scan_tmp[2][RS_WAVES];
 
+    const long long D = actual_count(cap, count_dev);
+    if ((long long)blockIdx.x * RS_TILE >= D) return;   // workgroup-uniform
+    const int ngroups = (int)(((D + RS_TILE - 1) / RS_TILE + RS_GROUP - 1) / RS_GROUP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) wave_cnt[w][tid] = 0;
@@ -210,9 +223,11 @@ extern "C" size_t gs_sort_workspace_bytes(long long D) {
 
 // Stable sort of (uint32 key, uint32 value) pairs on key bits [bit_begin, bit_end).  keys_a/vals_a hold
 // the input; *result_in_b tells which buffer pair holds the output (b after an odd number of passes).
-extern "C" int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint32_t* keys_a, uint32_t* vals_a,
-                             uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
-                             int* result_in_b, void* stream_) {
+// count_dev (device, may be NULL): sort min(*count_dev, D) pairs -- D is then only the capacity that
+// sizes grids and workspace, so the caller needs no host read-back of the pair count.
+extern "C" int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
+                             uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* workspace,
+                             size_t workspace_bytes, int* result_in_b, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GS_REQUIRE(D >= 0 && D < (1ll << 32) && result_in_b, "bad arguments");
     GS_REQUIRE(bit_begin >= 0 && bit_begin <= bit_end && bit_end <= 32, "bad bit range [%d,%d)", bit_begin, bit_end);
@@ -234,11 +249,11 @@ extern "C" int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint32_t* 
     for (int shift = bit_begin; shift < bit_end; shift += 8, ++pass) {
         uint32_t* grp = (uint32_t*)(grp0 + grp_bytes * pass);
         const uint32_t mask = bit_end - shift >= 8 ? 0xFFu : (1u << (bit_end - shift)) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, D, shift, mask, blk,
-                           grp);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, D, count_dev, shift, mask,
+                           blk, grp);
         GS_CHECK_LAUNCH("radix_hist");
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd, D, shift,
-                           mask, ngroups, blk, grp);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd, D,
+                           count_dev, shift, mask, blk, grp);
         GS_CHECK_LAUNCH("radix_scatter");
         uint32_t* tk = ks; ks = kd; kd = tk;
         uint32_t* tv = vs; vs = vd; vd = tv;

@@ -146,40 +146,86 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     ws_bytes = lib.gs_sort_workspace_bytes(N)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
     with _stage("sort_depth"):
-        _lib.check(lib.gs_sort_pairs(N, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
+        _lib.check(lib.gs_sort_pairs(N, None, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
                                        _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     order = ids[1 if in_b.value else 0][:N]
     offsets = torch.empty((N,), **i32)
     tiles_in_order = torch.empty((N,), **i32)
     total = torch.empty((1,), **i32)
     scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
-    host_total = C.c_uint32(0)
-    with _stage("scan_tiles"):
-        _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(tiles_in_order), _ptr(offsets), _ptr(total),
-                                     _ptr(scan_ws), C.byref(host_total), st), "gs_scan_tiles")
-    D = int(host_total.value)
     tiles_x, tiles_y = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     ntiles = tiles_x * tiles_y
-    keys_a = torch.empty((max(D, 1),), **i32)
-    keys_b = torch.empty((max(D, 1),), **i32)
-    vals_a = torch.empty((max(D, 1),), **i32)
-    vals_b = torch.empty((max(D, 1),), **i32)
-    with _stage("duplicate_with_keys"):
-        _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(order), _ptr(offsets), _ptr(tiles_in_order),
-                                              _ptr(keys_a), _ptr(vals_a), row_b, row_e, st),
-                   "gs_duplicate_with_keys")
-    # pairs were emitted far-to-near, so only the tile id is left to sort (stable)
-    bits = max(1, (ntiles - 1).bit_length())
-    ws_bytes = lib.gs_sort_workspace_bytes(D)
-    sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
-    with _stage("sort_pairs"):
-        _lib.check(lib.gs_sort_pairs(D, 0, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b),
-                                     _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
-    keys, point_list = (keys_b, vals_b) if in_b.value else (keys_a, vals_a)
-    ranges = torch.empty((ntiles, 2), **i32)
-    with _stage("identify_tile_ranges"):
-        _lib.check(lib.gs_identify_tile_ranges(D, ntiles, _ptr(keys), _ptr(ranges), st), "gs_identify_tile_ranges")
+
+    def bin_pairs(cap, count_dev):
+        """duplicate -> tile sort -> ranges into buffers of `cap` pairs; the pair count is `cap` itself
+        (count_dev None) or read by the kernels from device memory (no host round trip)."""
+        keys_a = torch.empty((max(cap, 1),), **i32)
+        keys_b = torch.empty((max(cap, 1),), **i32)
+        vals_a = torch.empty((max(cap, 1),), **i32)
+        vals_b = torch.empty((max(cap, 1),), **i32)
+        with _stage("duplicate_with_keys"):
+            _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(order), _ptr(offsets), _ptr(tiles_in_order),
+                                                  _ptr(keys_a), _ptr(vals_a), cap, row_b, row_e, st),
+                       "gs_duplicate_with_keys")
+        # pairs were emitted far-to-near, so only the tile id is left to sort (stable)
+        bits = max(1, (ntiles - 1).bit_length())
+        ws_bytes = lib.gs_sort_workspace_bytes(cap)
+        sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
+        with _stage("sort_pairs"):
+            _lib.check(lib.gs_sort_pairs(cap, _ptr(count_dev), 0, bits, _ptr(keys_a), _ptr(vals_a), _ptr(keys_b),
+                                         _ptr(vals_b), _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
+        keys, point_list = (keys_b, vals_b) if in_b.value else (keys_a, vals_a)
+        ranges = torch.empty((ntiles, 2), **i32)
+        with _stage("identify_tile_ranges"):
+            _lib.check(lib.gs_identify_tile_ranges(cap, _ptr(count_dev), ntiles, _ptr(keys), _ptr(ranges), st),
+                       "gs_identify_tile_ranges")
+        return keys, point_list, ranges
+
+    # The pair count D is only known on the device after the scan.  Reading it back before launching
+    # the rest stalls the GPU for ~0.1 ms per frame, so once a capacity is known from earlier frames
+    # on this device the rest is launched against that capacity with D taken from device memory,
+    # and D is checked afterwards (it arrived long before: the copy was queued right after the scan).
+    cap = _pair_capacity.get(dev.index, 0) if OPTIMISTIC_BINNING else 0
+    D = None
+    out = None
+    if cap > 0:
+        with _stage("scan_tiles"):
+            _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(tiles_in_order), _ptr(offsets),
+                                         _ptr(total), _ptr(scan_ws), None, st), "gs_scan_tiles")
+        pinned, event = _readback_slot(dev)
+        pinned.copy_(total, non_blocking=True)
+        event.record()
+        out = bin_pairs(cap, total)
+        event.synchronize()
+        D = int(pinned.item()) & 0xFFFFFFFF
+        if D > cap:        # estimate too small: pairs were dropped, redo with the exact count
+            out = None
+    else:
+        host_total = C.c_uint32(0)
+        with _stage("scan_tiles"):
+            _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(tiles_in_order), _ptr(offsets),
+                                         _ptr(total), _ptr(scan_ws), C.byref(host_total), st), "gs_scan_tiles")
+        D = int(host_total.value)
+    if out is None:
+        out = bin_pairs(D, None)
+    _pair_capacity[dev.index] = max(_pair_capacity.get(dev.index, 0), D + D // 4 + 4096)
+    keys, point_list, ranges = out
     return BinningState(splat, radii, tiles_touched, order, offsets, D, keys[:D], point_list[:D], ranges)
+
+
+# per-device state of the optimistic binning: pair capacity learnt from earlier frames, and a pinned
+# 4-byte slot + event for the asynchronous read-back of D
+OPTIMISTIC_BINNING = True
+_pair_capacity = {}
+_readback = {}
+
+
+def _readback_slot(dev):
+    slot = _readback.get(dev.index)
+    if slot is None:
+        slot = (torch.empty((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        _readback[dev.index] = slot
+    return slot
 
 
 class _RasterizeGaussians(torch.autograd.Function):

@@ -81,21 +81,26 @@ int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* or
                   uint32_t* offsets, uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream);
 /* keys[o] = tile id (row-major), vals[o] = Gaussian index i = order[r] (order == NULL: i = r), for
  * o in [offsets[r], offsets[r] + tiles_in_order[r]), tiles of one Gaussian in row-major order.
- * With order == NULL pass tiles_touched as tiles_in_order. */
+ * With order == NULL pass tiles_touched as tiles_in_order.  Pairs with o >= capacity (the number of
+ * pairs keys/vals can hold) are dropped, so a caller may size the buffers from an estimate, launch
+ * without reading D back first, and check D <= capacity afterwards. */
 int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
-                           const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals,
+                           const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals, long long capacity,
                            int tile_row_begin, int tile_row_end, void* stream);
 size_t gs_sort_workspace_bytes(long long D);
 /* Stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits [bit_begin, bit_end), 8 per
  * pass, at most 4 passes.  Input in (keys_a, vals_a); *result_in_b (host int) = 1 when the sorted
  * pairs ended in (keys_b, vals_b).  Used twice per frame: depth keys of the N Gaussians (bits 0..32)
- * and tile ids of the D pairs (bits 0..tile_bits). */
-int gs_sort_pairs(long long D, int bit_begin, int bit_end, uint32_t* keys_a, uint32_t* vals_a,
-                  uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
+ * and tile ids of the D pairs (bits 0..tile_bits).  count_dev (device pointer, may be NULL): the
+ * number of pairs is min(*count_dev, D) and D is only the capacity that sizes grids and workspace
+ * (gs_scan_tiles' total_dev can be passed straight in: no host read-back of the pair count). */
+int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
+                  uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
                   int* result_in_b, void* stream);
-/* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty). */
-int gs_identify_tile_ranges(long long D, int num_tiles, const uint32_t* keys, uint32_t* ranges,
-                            void* stream);
+/* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty); count_dev as
+ * in gs_sort_pairs. */
+int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, int num_tiles, const uint32_t* keys,
+                            uint32_t* ranges, void* stream);
 
 /*
  * Per-tile compositing.  Replaces splat_gaussians (gaussian_renderer/__init__.py:336-442).

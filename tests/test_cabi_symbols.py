@@ -39,7 +39,7 @@ def test_housekeeping_calls_work_without_a_gpu():
     assert lib.gs_scan_workspace_bytes(3_000_000) >= 4 * (3_000_000 // 4096)
     assert lib.gs_sort_workspace_bytes(7_535_647) >= 256 * 4 * (7_535_647 // 4096)
     # argument errors are reported through the return code + gs_last_error, never a crash
-    rc = lib.gs_identify_tile_ranges(-1, 0, None, None, None)
+    rc = lib.gs_identify_tile_ranges(-1, None, 0, None, None, None)
     assert rc == -1 and b"bad arguments" in lib.gs_last_error()
 
 

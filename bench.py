@@ -127,13 +127,22 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Untimed pass with HIP events around every stage: finds the dominant kernel and gives the
+    # per-stage breakdown.  (Two event records take ~10 us of stream time per stage, ~3 % of a
+    # frame, so the timed region below carries events around the dominant kernel only.)
     prof.enable()
+    for _ in range(3):
+        step()
+    stage_ms = prof.disable_and_collect()
+    dominant = max(stage_ms, key=stage_ms.get)
+    fence()
+    prof.enable(only=[dominant])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = step()
     fence()
     dt = time.perf_counter() - t0
-    stage_ms = prof.disable_and_collect()   # mean ms per launch, per stage, over the timed region
+    stage_ms[dominant] = prof.disable_and_collect()[dominant]   # mean ms per launch over the timed region
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -156,7 +165,6 @@ def main():
                     "preprocess_bwd": "preprocess_bwd", "sort_pairs": "radix_sort", "sort_depth": "depth_sort",
                     "duplicate_with_keys": "duplicate_with_keys", "scan_tiles": "scan",
                     "identify_tile_ranges": "identify_ranges"}
-        dominant = max(stage_ms, key=stage_ms.get)
         frame_bytes = sum(b.values())          # SURVEY.md 8d v1 model, unchanged by the depth pre-sort
         b["depth_sort"] = bytes_depth_sort(N)
         dom_bytes = b[stage_of[dominant]]

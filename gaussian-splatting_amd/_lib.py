@@ -27,7 +27,7 @@ PROTOTYPES = {
     "gs_sort_workspace_bytes": (_sz, [_ll]),
     "gs_sort_pairs": (_i, [_ll, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "gs_identify_tile_ranges": (_i, [_ll, _vp, _i, _vp, _vp, _vp]),
-    "gs_render_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "gs_render_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _sz, _vp]),
     "gs_render_bwd": (_i, [_i, _i] + [_vp] * 10 + [_f, _i, _i, _vp]),
 }
 

@@ -160,8 +160,18 @@ template <bool AUX>
 __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     int H, int W, int tiles_x, int tile0, int ntiles, const float* __restrict__ bg, const float4* __restrict__ splat,
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, float* __restrict__ out_img,
-    float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ aux_rgb, float t_eps) {
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ aux_rgb, float t_eps,
+    f4* __restrict__ zero_buf, size_t zero_n) {
     constexpr int BATCH = 256;
+    if (zero_buf) {
+        // This kernel is VALU-bound and leaves HBM nearly idle: clearing the backward's gradient-row
+        // buffer here (fire-and-forget 16-byte stores, one slice per workgroup) is free, a memset
+        // launched on its own costs ~24 us per frame at 3 M Gaussians.
+        const size_t chunk = (zero_n + gridDim.x - 1) / gridDim.x;
+        const size_t z0 = (size_t)blockIdx.x * chunk;
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        for (size_t j = threadIdx.x; j < chunk && z0 + j < zero_n; j += GS_BLOCK) zero_buf[z0 + j] = z;
+    }
     __shared__ f4 sq[3 * BATCH];
     __shared__ uint32_t wl_all[GS_BLOCK / 64][BATCH];
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
@@ -400,24 +410,30 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
 
 extern "C" int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32_t* ranges,
                              const uint32_t* point_list, float* out_image, float* out_depth, float* out_alpha,
-                             float* aux_rgb, float t_eps, int tile_row_begin, int tile_row_end, void* stream_) {
+                             float* aux_rgb, float t_eps, int tile_row_begin, int tile_row_end, void* zero_buf,
+                             size_t zero_bytes, void* stream_) {
     GS_REQUIRE(H > 0 && W > 0 && H < 65536 && W < 65536, "image size %dx%d outside 1..65535", W, H);
     GS_REQUIRE(bg && splat && ranges && out_image && out_depth && out_alpha, "null argument");
+    GS_REQUIRE(!zero_buf || ((((uintptr_t)zero_buf | zero_bytes) & 15) == 0), "zero_buf must be 16-byte aligned and sized");
+    if (!zero_buf) zero_bytes = 0;
     GS_REQUIRE(t_eps >= 0.0f && t_eps < 1.0f, "t_eps must be in [0,1)");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     GS_REQUIRE(tile_row_begin >= 0 && tile_row_begin <= tile_row_end, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
     if (tile_row_end > tiles_y) tile_row_end = tiles_y;
-    if (tile_row_begin >= tile_row_end) return GS_OK;
-    const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
     hipStream_t stream = (hipStream_t)stream_;
+    if (tile_row_begin >= tile_row_end) {
+        if (zero_bytes) GS_CHECK_HIP(hipMemsetAsync(zero_buf, 0, zero_bytes, stream));
+        return GS_OK;
+    }
+    const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
     if (aux_rgb)
         hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(ntiles), dim3(GS_BLOCK), 0, stream, H, W, tiles_x, tile0, ntiles,
                            bg, (const float4*)splat, (const uint2*)ranges, point_list, out_image, out_depth,
-                           out_alpha, aux_rgb, t_eps);
+                           out_alpha, aux_rgb, t_eps, (f4*)zero_buf, zero_bytes / 16);
     else
         hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(ntiles), dim3(GS_BLOCK), 0, stream, H, W, tiles_x, tile0, ntiles,
                            bg, (const float4*)splat, (const uint2*)ranges, point_list, out_image, out_depth,
-                           out_alpha, aux_rgb, t_eps);
+                           out_alpha, aux_rgb, t_eps, (f4*)zero_buf, zero_bytes / 16);
     GS_CHECK_LAUNCH("render_fwd");
     return GS_OK;
 }

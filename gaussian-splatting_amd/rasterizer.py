@@ -246,10 +246,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             aux = torch.empty((3, H, W), dtype=torch.float32, device=dev) if need_grad else None
+            # the backward's per-Gaussian gradient rows: cleared by the (VALU-bound) forward kernel for free
+            N = means3D.shape[0]
+            rows = torch.empty((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev) if need_grad else None
             with _stage("render_fwd"):
                 _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(state.splat), _ptr(state.ranges),
                                              _ptr(state.point_list), _ptr(image), _ptr(depth), _ptr(alpha),
-                                             _ptr(aux), float(t_eps), row_b, row_e, _stream()), "gs_render_fwd")
+                                             _ptr(aux), float(t_eps), row_b, row_e, _ptr(rows),
+                                             rows.numel() * 4 if rows is not None else 0, _stream()), "gs_render_fwd")
+        ctx.rows = rows
+        ctx.set_materialize_grads(False)   # unused outputs (depth, alpha) arrive as None, not as zero fills
         ctx.settings = settings
         ctx.t_eps = float(t_eps)
         ctx.band = (row_b, row_e)
@@ -298,7 +304,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_image = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
             g_depth = gin(g_depth, (1, H, W))
             g_alpha = gin(g_alpha, (1, H, W))
-            rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
+            rows, ctx.rows = ctx.rows, None          # cleared by the forward; a second backward clears its own
+            if rows is None:
+                rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
             with _stage("render_bwd"):
                 _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux),
                                              _ptr(depth), _ptr(alpha), _ptr(g_image), _ptr(g_depth),

@@ -108,10 +108,14 @@ int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, int num_tile
  * optional, receives sum alpha_i c_i without bg (needed by gs_render_bwd).  t_eps in [0,1): a pixel
  * stops once 1 - alpha_acc < t_eps; 0 = never (the reference's exact semantics).  Only pixels of
  * tile rows [tile_row_begin, tile_row_end) are computed and written.
+ * zero_buf / zero_bytes (optional, 16-byte aligned, multiple of 16): a buffer to clear on the side --
+ * meant for gs_render_bwd's grad_rows: this kernel is VALU-bound and leaves HBM idle, so the clear
+ * is free here while a separate memset costs its full HBM time.
  */
 int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32_t* ranges,
                   const uint32_t* point_list, float* out_image, float* out_depth, float* out_alpha,
-                  float* aux_rgb, float t_eps, int tile_row_begin, int tile_row_end, void* stream);
+                  float* aux_rgb, float t_eps, int tile_row_begin, int tile_row_end, void* zero_buf,
+                  size_t zero_bytes, void* stream);
 
 /*
  * Backward of gs_render_fwd (the reference gets it from torch autograd).  g_image (3,H,W),

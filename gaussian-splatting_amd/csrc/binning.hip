@@ -8,36 +8,31 @@
 // tile's list far-to-near.  Bit-exact against oracle/gs_oracle.c (gso_duplicate_with_keys +
 // gso_sort_pairs on tile_id << 32 | depth_key give the same list).
 //
-// HBM-bound: 32 B of the record gathered + 12 B (id, offset, count) read per Gaussian, 8 B
-// written per pair.
+// HBM-bound: 16 B (box, id, offset) read per Gaussian, all coalesced (the boxes were gathered into
+// depth order by gs_scan_tiles), 8 B written per pair.
 #include "gsplat_common.h"
 
 namespace {
 
 __global__ __launch_bounds__(256) void duplicate_with_keys_kernel(int N, int tiles_x, int row_b, int row_e,
                                                                    const uint32_t* __restrict__ order,
-                                                                   const float4* __restrict__ splat,
+                                                                   const uint2* __restrict__ rect_in_order,
                                                                    const uint32_t* __restrict__ offsets,
-                                                                   const uint32_t* __restrict__ tiles_in_order,
                                                                    uint32_t* __restrict__ keys,
                                                                    uint32_t* __restrict__ vals, size_t capacity) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= N) return;
-    if (tiles_in_order[r] == 0) return;
-    // lane r emits the Gaussian of depth rank r at offsets[r]
-    const int i = order ? (int)order[r] : r;
-    const uint32_t rx = __float_as_uint(splat[3 * (size_t)i + 1].w), ry = __float_as_uint(splat[3 * (size_t)i + 2].w);
-    const int xmin = rx & 0xFFFF, xmax = rx >> 16, ymin = ry & 0xFFFF, ymax = ry >> 16;
-    const int tx0 = xmin / GS_TILE, tx1 = (xmax - 1) / GS_TILE + 1;
-    int ty0 = ymin / GS_TILE, ty1 = (ymax - 1) / GS_TILE + 1;
-    ty0 = ty0 > row_b ? ty0 : row_b;
-    ty1 = ty1 < row_e ? ty1 : row_e;
+    // lane r emits the Gaussian of depth rank r at offsets[r]; all reads are coalesced
+    const uint2 rect = rect_in_order[r];
+    GsTileSpan t;
+    if (gs_tile_span(rect.x, rect.y, row_b, row_e, t) == 0) return;
+    const uint32_t i = order[r];
     size_t o = offsets[r];
-    for (int ty = ty0; ty < ty1; ++ty)
-        for (int tx = tx0; tx < tx1; ++tx) {
+    for (int ty = t.ty0; ty < t.ty1; ++ty)
+        for (int tx = t.tx0; tx < t.tx1; ++tx) {
             if (o < capacity) {   // pairs beyond the caller's buffers are dropped (the caller checks D afterwards)
                 keys[o] = (uint32_t)(ty * tiles_x + tx);
-                vals[o] = (uint32_t)i;
+                vals[o] = i;
             }
             ++o;
         }
@@ -61,16 +56,16 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long cap
 
 }  // namespace
 
-extern "C" int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
-                                      const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals,
-                                      long long capacity, int tile_row_begin, int tile_row_end, void* stream_) {
+extern "C" int gs_duplicate_with_keys(int N, int W, const void* rect_in_order, const uint32_t* order,
+                                      const uint32_t* offsets, uint32_t* keys, uint32_t* vals, long long capacity,
+                                      int tile_row_begin, int tile_row_end, void* stream_) {
     GS_REQUIRE(N >= 0 && W > 0 && capacity >= 0, "bad arguments");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(splat && offsets && tiles_in_order && keys && vals, "null buffer");
+    GS_REQUIRE(rect_in_order && order && offsets && keys && vals, "null buffer");
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, (hipStream_t)stream_, N,
-                       tiles_x, tile_row_begin, tile_row_end, order, (const float4*)splat, offsets, tiles_in_order, keys,
-                       vals, (size_t)capacity);
+                       tiles_x, tile_row_begin, tile_row_end, order, (const uint2*)rect_in_order, offsets, keys, vals,
+                       (size_t)capacity);
     GS_CHECK_LAUNCH("duplicate_with_keys");
     return GS_OK;
 }

@@ -72,3 +72,16 @@ __device__ __forceinline__ uint32_t gs_depth_key_desc(float z) {
     uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ~asc;
 }
+
+// Tiles overlapped by a packed box (rect_x = x_min | x_max << 16, rect_y likewise; half-open, pixels)
+// inside the band of tile rows [row_b, row_e).  An all-zero box (Gaussian not drawn) has no tiles.
+struct GsTileSpan { int tx0, tx1, ty0, ty1; };
+__device__ __forceinline__ uint32_t gs_tile_span(uint32_t rect_x, uint32_t rect_y, int row_b, int row_e, GsTileSpan& t) {
+    const int xmin = rect_x & 0xFFFF, xmax = rect_x >> 16, ymin = rect_y & 0xFFFF, ymax = rect_y >> 16;
+    if (xmax <= xmin || ymax <= ymin) { t.tx0 = t.tx1 = t.ty0 = t.ty1 = 0; return 0u; }
+    t.tx0 = xmin / GS_TILE; t.tx1 = (xmax - 1) / GS_TILE + 1;
+    t.ty0 = ymin / GS_TILE; t.ty1 = (ymax - 1) / GS_TILE + 1;
+    t.ty0 = t.ty0 > row_b ? t.ty0 : row_b;
+    t.ty1 = t.ty1 < row_e ? t.ty1 : row_e;
+    return t.ty1 > t.ty0 ? (uint32_t)((t.tx1 - t.tx0) * (t.ty1 - t.ty0)) : 0u;
+}

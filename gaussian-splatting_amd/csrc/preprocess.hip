@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const float* __restrict__ cov6, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids) {
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids, uint2* __restrict__ rects) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     Geom g;
@@ -245,6 +245,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     if (depth_keys) {   // input of the per-Gaussian depth sort; culled Gaussians sort last
         depth_keys[i] = g.drawn ? gs_depth_key_desc(g.cam[2]) : 0xFFFFFFFFu;
         ids[i] = (uint32_t)i;
+        // compact copy of the box (all zero when not drawn) for the binning stage's one gather
+        rects[i] = make_uint2((uint32_t)g.xmin | ((uint32_t)g.xmax << 16), (uint32_t)g.ymin | ((uint32_t)g.ymax << 16));
     }
     if (!g.drawn) return;
     float rgb[3];
@@ -563,15 +565,15 @@ template <int DEG>
 int launch_fwd(bool vec4, int N, int K, int H, int W, int row_b, int row_e, const float* view, const float* proj,
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* opac, const float* shs, const float* colors,
-               float4* splat, int32_t* radii, uint32_t* tiles, uint32_t* depth_keys, uint32_t* ids,
+               float4* splat, int32_t* radii, uint32_t* tiles, uint32_t* depth_keys, uint32_t* ids, uint2* rects,
                hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
     if (vec4)
         hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
-                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids);
+                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids, rects);
     else
         hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
-                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids);
+                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids, rects);
     GS_CHECK_LAUNCH("preprocess_fwd");
     return GS_OK;
 }
@@ -616,14 +618,16 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
                                  const float* scales, const float* rotations, const float* cov3D_precomp,
                                  const float* opacities, const float* shs, const float* colors_precomp,
                                  void* splat, int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                                 uint32_t* ids, int tile_row_begin, int tile_row_end, void* stream_) {
+                                 uint32_t* ids, void* rects, int tile_row_begin, int tile_row_end, void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
     GS_REQUIRE(viewmatrix && projmatrix && campos && opacities && splat && radii && tiles_touched, "null argument");
     GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
     GS_REQUIRE(((uintptr_t)splat & 15) == 0, "splat buffer must be 16-byte aligned");
-    GS_REQUIRE((depth_keys == nullptr) == (ids == nullptr), "depth_keys and ids go together");
+    GS_REQUIRE((depth_keys == nullptr) == (ids == nullptr) && (ids == nullptr) == (rects == nullptr),
+               "depth_keys, ids and rects go together");
+    GS_REQUIRE(((uintptr_t)rects & 7) == 0, "rects must be 8-byte aligned");
     GS_REQUIRE(tile_row_begin >= 0 && tile_row_end >= tile_row_begin, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -631,10 +635,10 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
     const int deg = shs ? sh_degree : 0;
     float4* sp = (float4*)splat;
     switch (deg) {
-        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
-        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
-        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
-        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, stream);
+        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
+        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
+        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
+        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
     }
 }
 

@@ -136,12 +136,13 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     # depth keys / Gaussian ids, ping-pong buffers of the per-Gaussian depth sort
     dkeys = torch.empty((2, max(N, 1)), **i32)
     ids = torch.empty((2, max(N, 1)), **i32)
+    rects = torch.empty((max(N, 1), 2), **i32)
     with _stage("preprocess_fwd"):
         _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
                                          _ptr(radii), _ptr(tiles_touched), _ptr(dkeys[0]), _ptr(ids[0]),
-                                         row_b, row_e, st), "gs_preprocess_fwd")
+                                         _ptr(rects), row_b, row_e, st), "gs_preprocess_fwd")
     in_b = C.c_int(0)
     ws_bytes = lib.gs_sort_workspace_bytes(N)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
@@ -150,7 +151,7 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
                                        _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     order = ids[1 if in_b.value else 0][:N]
     offsets = torch.empty((N,), **i32)
-    tiles_in_order = torch.empty((N,), **i32)
+    rect_in_order = torch.empty((max(N, 1), 2), **i32)
     total = torch.empty((1,), **i32)
     scan_ws = torch.empty((max(16, lib.gs_scan_workspace_bytes(N)),), dtype=torch.uint8, device=dev)
     tiles_x, tiles_y = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
@@ -164,7 +165,7 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
         vals_a = torch.empty((max(cap, 1),), **i32)
         vals_b = torch.empty((max(cap, 1),), **i32)
         with _stage("duplicate_with_keys"):
-            _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(splat), _ptr(order), _ptr(offsets), _ptr(tiles_in_order),
+            _lib.check(lib.gs_duplicate_with_keys(N, W, _ptr(rect_in_order), _ptr(order), _ptr(offsets),
                                                   _ptr(keys_a), _ptr(vals_a), cap, row_b, row_e, st),
                        "gs_duplicate_with_keys")
         # pairs were emitted far-to-near, so only the tile id is left to sort (stable)
@@ -190,8 +191,9 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     out = None
     if cap > 0:
         with _stage("scan_tiles"):
-            _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(tiles_in_order), _ptr(offsets),
-                                         _ptr(total), _ptr(scan_ws), None, st), "gs_scan_tiles")
+            _lib.check(lib.gs_scan_tiles(N, _ptr(rects), _ptr(order), _ptr(rect_in_order),
+                                         _ptr(offsets), _ptr(total), _ptr(scan_ws), None, row_b, row_e, st),
+                       "gs_scan_tiles")
         pinned, event = _readback_slot(dev)
         pinned.copy_(total, non_blocking=True)
         event.record()
@@ -203,8 +205,9 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     else:
         host_total = C.c_uint32(0)
         with _stage("scan_tiles"):
-            _lib.check(lib.gs_scan_tiles(N, _ptr(tiles_touched), _ptr(order), _ptr(tiles_in_order), _ptr(offsets),
-                                         _ptr(total), _ptr(scan_ws), C.byref(host_total), st), "gs_scan_tiles")
+            _lib.check(lib.gs_scan_tiles(N, _ptr(rects), _ptr(order), _ptr(rect_in_order),
+                                         _ptr(offsets), _ptr(total), _ptr(scan_ws), C.byref(host_total), row_b,
+                                         row_e, st), "gs_scan_tiles")
         D = int(host_total.value)
     if out is None:
         out = bin_pairs(D, None)

@@ -54,8 +54,9 @@ int gs_grad_row_floats(void);    /* 16: floats per per-Gaussian gradient row (se
  * BASELINE.json config 5); radii are independent of the band.
  * Outputs: splat (N x 12 floats, 48-byte records, layout in csrc/gsplat_common.h; rows of culled
  * Gaussians are not written), radii (N) int32 = ceil(3 sigma_max) or 0 when not drawn,
- * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.  depth_keys / ids (N each,
- * both or neither NULL): input of the per-Gaussian depth sort, depth_keys[i] = 32-bit key whose
+ * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.  depth_keys / ids (N each) /
+ * rects (N x 2 uint32: x_min | x_max << 16, y_min | y_max << 16; all zero when not drawn), all three
+ * or none NULL: input of the binning stage, depth_keys[i] = 32-bit key whose
  * ascending order is descending depth (0xFFFFFFFF for Gaussians that are not drawn, so they sort last), ids[i] = i.
  */
 int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
@@ -63,7 +64,7 @@ int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* vi
                       const float* scales, const float* rotations, const float* cov3D_precomp,
                       const float* opacities, const float* shs, const float* colors_precomp,
                       void* splat, int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                      uint32_t* ids, int tile_row_begin, int tile_row_end, void* stream);
+                      uint32_t* ids, void* rects, int tile_row_begin, int tile_row_end, void* stream);
 
 /*
  * Binning stage.  The reference has one global far-to-near order (torch.argsort at
@@ -74,19 +75,20 @@ int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* vi
  * every tile's list far-to-near.
  */
 size_t gs_scan_workspace_bytes(long long N);
-/* offsets[r] = exclusive scan of tiles_touched[order[r]] and tiles_in_order[r] = tiles_touched[order[r]]
- * (order == NULL: plain exclusive scan of tiles_touched, tiles_in_order unused); *total_dev = D;
- * host_total (host pointer, may be NULL) receives D after a stream synchronise. */
-int gs_scan_tiles(long long N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* tiles_in_order,
-                  uint32_t* offsets, uint32_t* total_dev, void* workspace, uint32_t* host_total, void* stream);
-/* keys[o] = tile id (row-major), vals[o] = Gaussian index i = order[r] (order == NULL: i = r), for
- * o in [offsets[r], offsets[r] + tiles_in_order[r]), tiles of one Gaussian in row-major order.
- * With order == NULL pass tiles_touched as tiles_in_order.  Pairs with o >= capacity (the number of
- * pairs keys/vals can hold) are dropped, so a caller may size the buffers from an estimate, launch
- * without reading D back first, and check D <= capacity afterwards. */
-int gs_duplicate_with_keys(int N, int W, const void* splat, const uint32_t* order, const uint32_t* offsets,
-                           const uint32_t* tiles_in_order, uint32_t* keys, uint32_t* vals, long long capacity,
-                           int tile_row_begin, int tile_row_end, void* stream);
+/* For every depth rank r: rect_in_order[r] (N x 2 uint32) = rects[order[r]], the box of the Gaussian
+ * of that rank, and offsets[r] = exclusive scan of the number of tiles of those boxes inside the band
+ * of tile rows.  *total_dev = D; host_total (host pointer, may be NULL) receives D after a stream
+ * synchronise.  This gather is the only random access of the binning stage. */
+int gs_scan_tiles(long long N, const void* rects, const uint32_t* order, void* rect_in_order, uint32_t* offsets,
+                  uint32_t* total_dev, void* workspace, uint32_t* host_total, int tile_row_begin,
+                  int tile_row_end, void* stream);
+/* keys[o] = tile id (row-major), vals[o] = Gaussian index order[r], for o in [offsets[r], offsets[r] +
+ * tiles of rect_in_order[r]), tiles of one Gaussian in row-major order.  Pairs with o >= capacity (the
+ * number of pairs keys/vals can hold) are dropped, so a caller may size the buffers from an estimate,
+ * launch without reading D back first, and check D <= capacity afterwards. */
+int gs_duplicate_with_keys(int N, int W, const void* rect_in_order, const uint32_t* order, const uint32_t* offsets,
+                           uint32_t* keys, uint32_t* vals, long long capacity, int tile_row_begin,
+                           int tile_row_end, void* stream);
 size_t gs_sort_workspace_bytes(long long D);
 /* Stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits [bit_begin, bit_end), 8 per
  * pass, at most 4 passes.  Input in (keys_a, vals_a); *result_in_b (host int) = 1 when the sorted

@@ -117,9 +117,11 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
 // wl[] (in list order).  When posmap is given, posmap[j] = position of pair j in the wave's
 // compacted list, 0xFFFF if culled, and sid[j] = Gaussian id.  Returns the wave's hit count.
 template <int BATCH>
-__device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
+__device__ __forceinline__ int stage_and_cull(  // BATCH: multiple of 64, at most GS_BLOCK
+const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
                                               uint32_t* wl, uint16_t* posmap) {
+    static_assert(BATCH % 64 == 0 && BATCH >= 64 && BATCH <= GS_BLOCK, "one staging lane per pair, whole waves of cull lanes");
     const int tid = threadIdx.x;
     if (tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
     const float* __restrict__ g_depth, const float* __restrict__ g_alpha, float* __restrict__ grad_rows,
     float t_eps) {
-    constexpr int BATCH = 128;
+    constexpr int BATCH = 64;
     constexpr int NW = GS_BLOCK / 64;
     __shared__ f4 sq[3 * BATCH];
     __shared__ uint32_t sid[BATCH];

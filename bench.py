@@ -169,9 +169,22 @@ def main():
         b["depth_sort"] = bytes_depth_sort(N)
         dom_bytes = b[stage_of[dominant]]
         achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc cannot run inside this process:
+        # they are collected by tools/pmc_hbm.sh on this same command and committed under profiles/)
+        traffic, traffic_src = None, None
+        if args.config == "config3_garden_3M_sh3_1297x840" and args.t_eps is None:
+            try:
+                tab = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+                traffic = tab["kernels"][dominant + "_kernel"]["traffic_bytes"]
+                traffic_src = tab["source"]
+            except (OSError, KeyError, ValueError):
+                pass
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4)}
+                    "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4),
+                    "limiter": "VALU issue (SQ_ACTIVE_INST_VALU x4 / SIMD cycles = 92 % in render_bwd, "
+                               "profiles/r1c_pmc_sq_counters.txt); HBM accounting kept as the task prescribes"}
         out = {
             "metric": "Mpix/s fwd+bwd @3M Gaussians SH3", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

@@ -80,30 +80,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_rect_kernel(
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// Striped arrangement so that every load and store is coalesced: wave w of the workgroup owns 1024
+// consecutive elements and walks them in 16 rounds of 64.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_rect_kernel(const uint2* __restrict__ rect, long long n,
                                                                         int row_b, int row_e,
                                                                         const uint32_t* __restrict__ block_sums,
                                                                         uint32_t* __restrict__ out) {
-    __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    __shared__ uint32_t wave_total[SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)wave * (64 * SCAN_ITEMS) + lane;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const long long idx = base + j * 64;
         v[j] = 0u;
-        if (base + j < n) {
-            const uint2 r = rect[base + j];
+        if (idx < n) {
+            const uint2 r = rect[idx];
             GsTileSpan t;
             v[j] = gs_tile_span(r.x, r.y, row_b, row_e, t);
         }
         s += v[j];
     }
-    uint32_t total;
-    uint32_t run = block_excl_scan(s, lds_wave, total) + block_sums[blockIdx.x];
+    const uint32_t wsum = wave_incl_scan(s, lane);   // lane 63: this wave's total
+    if (lane == 63) wave_total[wave] = wsum;
+    __syncthreads();
+    uint32_t run = block_sums[blockIdx.x];
+    for (int w = 0; w < wave; ++w) run += wave_total[w];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < n) out[base + j] = run;
-        run += v[j];
+        const long long idx = base + j * 64;
+        const uint32_t incl = wave_incl_scan(v[j], lane);
+        if (idx < n) out[idx] = run + incl - v[j];
+        run += __shfl(incl, 63, 64);
     }
 }
 

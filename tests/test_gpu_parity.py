@@ -249,3 +249,101 @@ def test_tile_row_bands_equal_full_frame(dgr):
                 cat = torch.cat([b[i] for b in bands], dim=1)
                 ref = full[{0: 0, 1: 2, 2: 3}[i]]
                 assert torch.equal(cat, ref), f"{name} bands differ from the full frame (world={world})"
+
+
+def _bin_state(dgr, sc, dev):
+    inp = _scene_inputs(sc, dev)
+    st = dgr.preprocess_and_bin(_scene_settings(dgr, sc, dev), inp["means3D"], inp["opacities"], inp["scales"],
+                                inp["rotations"], None, inp["shs"], None)
+    torch.cuda.synchronize()
+    return st
+
+
+def test_optimistic_binning_equals_exact_and_recovers_from_overflow(dgr):
+    """The read-back-free binning (capacity learnt from earlier frames, D taken from device memory) gives
+    the same lists as the exact path, also when the learnt capacity is too small and the frame is redone."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    rz = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    dev = torch.device("cuda:0")
+    small = syn.make_scene(3000, 16, 96, 128, seed=11)
+    big = syn.make_scene(40000, 16, 203, 317, seed=12)
+    saved = dict(rz._pair_capacity)
+    try:
+        rz.OPTIMISTIC_BINNING = False
+        exact = _bin_state(dgr, big, dev)
+        rz.OPTIMISTIC_BINNING = True
+        rz._pair_capacity.clear()
+        _bin_state(dgr, small, dev)                     # learns a capacity far below the big frame's D
+        cap = rz._pair_capacity[dev.index]
+        assert cap < exact.num_pairs
+        over = _bin_state(dgr, big, dev)                # overflows -> redone with the exact count
+        assert rz._pair_capacity[dev.index] >= exact.num_pairs
+        opt = _bin_state(dgr, big, dev)                 # now runs optimistically within capacity
+        for name, st in (("overflow", over), ("optimistic", opt)):
+            assert st.num_pairs == exact.num_pairs, name
+            for f in ("keys", "point_list", "ranges", "offsets", "order"):
+                assert torch.equal(getattr(st, f), getattr(exact, f)), f"{name}: {f} differs"
+    finally:
+        rz.OPTIMISTIC_BINNING = True
+        rz._pair_capacity.clear()
+        rz._pair_capacity.update(saved)
+
+
+@pytest.mark.parametrize("n,bits,use_count", [(0, 32, False), (1, 32, False), (5000, 32, False), (70000, 13, False),
+                                              (70000, 13, True), (300000, 32, True), (4097, 5, False)])
+def test_sort_pairs_stable_on_bit_range(n, bits, use_count):
+    """gs_sort_pairs through the C-ABI against numpy's stable argsort on the masked key; with use_count
+    the pair count comes from device memory and the buffers are larger than it (capacity)."""
+    import ctypes as C
+    lib = importlib.import_module("gaussian-splatting_amd._lib")
+    L = lib.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + bits)
+    cap = n + 5000 if use_count else n
+    keys = rng.integers(0, 2 ** 32, size=max(cap, 1), dtype=np.uint64).astype(np.uint32)
+    if bits < 32:
+        keys[: n // 2] &= np.uint32(0x3)              # skewed digits: many equal keys, stability matters
+    vals = np.arange(max(cap, 1), dtype=np.uint32)
+    t = lambda a: torch.from_numpy(a.view(np.int32).copy()).to(dev)  # noqa: E731
+    ka, va = t(keys), t(vals)
+    kb, vb = torch.empty_like(ka), torch.empty_like(va)
+    ws_bytes = L.gs_sort_workspace_bytes(cap)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev) if use_count else None
+    in_b = C.c_int(0)
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
+    rc = L.gs_sort_pairs(cap, p(cnt), 0, bits, p(ka), p(va), p(kb), p(vb), p(ws), ws_bytes, C.byref(in_b),
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gs_last_error()
+    torch.cuda.synchronize()
+    ko, vo = (kb, vb) if in_b.value else (ka, va)
+    mask = np.uint32((1 << bits) - 1) if bits < 32 else np.uint32(0xFFFFFFFF)
+    perm = np.argsort(keys[:n] & mask, kind="stable")
+    assert np.array_equal(ko.cpu().numpy().view(np.uint32)[:n], keys[:n][perm])
+    assert np.array_equal(vo.cpu().numpy().view(np.uint32)[:n], vals[:n][perm])
+
+
+def test_backward_twice_and_unused_outputs(dgr):
+    """retain_graph: the second backward clears its own gradient rows (the first used the rows the
+    forward kernel cleared); a loss on depth alone leaves the image gradient undefined (None)."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    sc = syn.make_scene(5000, 16, 96, 128, seed=13)
+    dev = torch.device("cuda:0")
+    inp = {k: v.clone().requires_grad_(True) for k, v in _scene_inputs(sc, dev).items()}
+    rast = dgr.GaussianRasterizer(_scene_settings(dgr, sc, dev), t_eps=0.0)
+    image, radii, depth, alpha = rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"],
+                                      opacities=inp["opacities"], scales=inp["scales"], rotations=inp["rotations"])
+    loss = (image * sc.G.to(dev)).sum() + depth.sum()
+    loss.backward(retain_graph=True)
+    g1 = {k: v.grad.clone() for k, v in inp.items()}
+    for v in inp.values():
+        v.grad = None
+    loss.backward()
+    for k, v in inp.items():
+        check_grad("twice:d_" + k, v.grad.cpu().numpy(), g1[k].cpu().numpy(), rel=1e-5)   # atomics reorder sums
+    for v in inp.values():
+        v.grad = None
+    image, radii, depth, alpha = rast(means3D=inp["means3D"], means2D=None, shs=inp["shs"],
+                                      opacities=inp["opacities"], scales=inp["scales"], rotations=inp["rotations"])
+    depth.sum().backward()
+    assert float(inp["shs"].grad.abs().max()) == 0.0 and float(inp["means3D"].grad.abs().max()) > 0.0

@@ -130,18 +130,19 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
 // the byte offsets (48 j) of the records whose box overlaps that block, in list order.  Lists
 // shorter than the longest are padded with the offset of a record no lane is ever inside
 // (sq[BATCH]), so the per-visit loop needs no "is my list exhausted" test.  wl = this wave's lists,
-// GS_ROWS x BATCH entries; posmap (optional, same shape, u16) = position of pair j in each list,
+// GS_ROWS x (BATCH + 1) entries (one spare for the loop's prefetch); posmap (optional, GS_ROWS x BATCH, u16) = position of pair j in each list,
 // 0xFFFF when it is not in it.  Returns the length of the longest list.
 template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
-                                              uint32_t* wl, uint16_t* posmap) {
+                                              uint32_t* wl, uint16_t* posmap, f4* conic = nullptr) {
     static_assert(BATCH % 32 == 0 && BATCH >= 32 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
     if (tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];
         const f4* p = splat + 3 * (size_t)id;
         f4 p0 = p[0], p1 = p[1], p2 = p[2];
+        if (conic) conic[tid] = f4{p0.z, p0.w, p1.x, 0.f};
         to_lds_form(p0, p1, p2);
         sq[3 * tid] = p0;
         sq[3 * tid + 1] = p1;
@@ -170,7 +171,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         for (int q = 0; q < GS_ROWS; ++q) {
             const uint64_t m = __ballot(hit[q]);
             const int pos = cnt[q] + __popcll(m & lt);
-            if (hit[q]) wl[q * BATCH + pos] = 48u * (uint32_t)j;
+            if (hit[q]) wl[q * (BATCH + 1) + pos] = 48u * (uint32_t)j;
             if (posmap && j < BATCH) posmap[q * BATCH + j] = hit[q] ? (uint16_t)pos : (uint16_t)0xFFFF;
             cnt[q] += __popcll(m);
         }
@@ -178,7 +179,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     const int nmax = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
 #pragma unroll
     for (int q = 0; q < GS_ROWS; ++q)
-        for (int p = cnt[q] + lane; p < nmax; p += 64) wl[q * BATCH + p] = 48u * (uint32_t)BATCH;
+        for (int p = cnt[q] + lane; p < nmax; p += 64) wl[q * (BATCH + 1) + p] = 48u * (uint32_t)BATCH;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return nmax;
@@ -211,12 +212,12 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
         for (size_t j = threadIdx.x; j < chunk && z0 + j < zero_n; j += GS_BLOCK) zero_buf[z0 + j] = z;
     }
     __shared__ f4 sq[3 * (BATCH + 1)];
-    __shared__ uint32_t wl_all[NW][GS_ROWS * BATCH];
+    __shared__ uint32_t wl_all[NW][GS_ROWS * (BATCH + 1)];
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int lane = threadIdx.x & 63;
     uint32_t* wl = wl_all[threadIdx.x >> 6];
-    const uint32_t* mylist = wl + (lane >> 4) * BATCH;
+    const uint32_t* mylist = wl + (lane >> 4) * (BATCH + 1);
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
     float A = 0.f, T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Z = 0.f;
@@ -226,9 +227,11 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
         if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
         const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr);
+        uint32_t off_next = mylist[0];   // list entry one visit ahead: one LDS latency per visit, not two
         for (int kk = 0; kk < nmax; ++kk) {
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
-            const Rec rec = load_rec(sq, mylist[kk]);
+            const Rec rec = load_rec(sq, off_next);
+            off_next = mylist[kk + 1];       // entry nmax is never used (lists have BATCH + 1 entries)
             const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
             const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
             const float power2 = gauss_power2(rec, dx, dy);
@@ -313,15 +316,16 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     constexpr int SLOT = 10;                    // floats per (block, list position) slot
     __shared__ f4 sq[3 * (BATCH + 1)];
     __shared__ uint32_t sid[BATCH];
-    __shared__ uint32_t wl_all[NW][GS_ROWS * BATCH];
+    __shared__ uint32_t wl_all[NW][GS_ROWS * (BATCH + 1)];
     __shared__ uint16_t posmap_all[NW][GS_ROWS * BATCH];
-    __shared__ float slots[NBLK * BATCH * SLOT];     // plain stores, one 40-byte slot per row visit
+    __shared__ float slots[(NBLK * BATCH + 1) * SLOT];   // plain stores, one 40-byte slot per row visit (+ a zero slot)
+    __shared__ f4 conic[BATCH];                      // unscaled (a, b, d) of every pair for the flush
     __shared__ uint64_t visited_all[NW];             // bit kk: the wave executed (did not skip) visit kk
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* wl = wl_all[wave];
-    const uint32_t* mylist = wl + (lane >> 4) * BATCH;
+    const uint32_t* mylist = wl + (lane >> 4) * (BATCH + 1);
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
     float gr = 0.f, gg = 0.f, gb = 0.f, gz = 0.f, ga = 0.f, total = 0.f;
@@ -347,14 +351,18 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     // this lane's float inside slot 0 of its row's block
     float* my_slot = slots + (size_t)(wave * GS_ROWS + (lane >> 4)) * BATCH * SLOT + (red_slot < 0 ? 0 : red_slot);
     write_pad_record(sq, BATCH);
+    if (tid < SLOT) slots[NBLK * BATCH * SLOT + tid] = 0.0f;
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
-        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave]);
+        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
+                                               conic);
         uint64_t visited = 0;
+        uint32_t off_next = mylist[0];
         for (int kk = 0; kk < nmax; ++kk) {
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
-            const Rec rec = load_rec(sq, mylist[kk]);
+            const Rec rec = load_rec(sq, off_next);
+            off_next = mylist[kk + 1];
             const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
             if (!__any(act)) continue;
             visited |= 1ull << kk;
@@ -397,26 +405,29 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         // q dy, q dx^2, q dx dy, q dy^2); the gradient row is
         //   d mean = (a Sx + b Sy, d Sy + b Sx),  d conic = -0.5 (Sxx, Sxy, Syy).
         const int blk = tid & 15;
+        const uint64_t blk_visited = visited_all[blk >> 2];
+        const uint16_t* blk_posmap = posmap_all[blk >> 2] + (blk & 3) * BATCH;
+        const float* blk_slots = slots + (size_t)blk * BATCH * SLOT;
 #pragma unroll
         for (int r = 0; r < BATCH / 16; ++r) {
             const int j = r * 16 + (tid >> 4);
-            const uint32_t pos = posmap_all[blk >> 2][(blk & 3) * BATCH + j];
-            const bool valid = j < n && pos != 0xFFFFu && ((visited_all[blk >> 2] >> pos) & 1ull);
+            const uint32_t pos = blk_posmap[j];
+            const bool valid = j < n && pos != 0xFFFFu && ((blk_visited >> pos) & 1ull);
             const uint64_t vm = __ballot(valid);
+            if (vm == 0) continue;                   // wave-uniform: none of this wave's 4 pairs was visited
             const bool any = ((vm >> (lane & 48)) & 0xFFFFull) != 0;
+            // lanes without a slot read the always-zero slot behind the last one
+            const float* sl = valid ? blk_slots + pos * SLOT : slots + NBLK * BATCH * SLOT;
             float v[10];
-            const float* sl = slots + ((size_t)blk * BATCH + (valid ? pos : 0)) * SLOT;
 #pragma unroll
-            for (int k = 0; k < 10; ++k) v[k] = valid ? sl[k] : 0.0f;
+            for (int k = 0; k < 10; ++k) v[k] = sl[k];
             const float sum = row_reduce_scatter10(v, t);
             const float other = __shfl_xor(sum, 1);
             if (any && red_slot >= 0) {
                 float outv = sum;
                 if (red_slot < 2) {
-                    const float* rq = (const float*)&sq[3 * j];
-                    const float ca = rq[2] * (-2.0f / GS_LOG2E), cb = rq[3] * (-1.0f / GS_LOG2E),
-                                cd = rq[4] * (-2.0f / GS_LOG2E);
-                    outv = (red_slot == 0 ? ca : cd) * sum + cb * other;
+                    const f4 cn = conic[j];           // (a, b, d) as preprocess wrote them
+                    outv = (red_slot == 0 ? cn.x : cn.z) * sum + cn.y * other;
                 } else if (red_slot < 5) {
                     outv = -0.5f * sum;
                 }

@@ -287,7 +287,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 constexpr int BWD_STAGE_MAX_ROW = 48;
 constexpr int BWD_STAGE_STRIDE = BWD_STAGE_MAX_ROW + 1;   // odd stride: per-lane rows hit all banks
 
-template <int DEG, int MODE>
+// PART 0: everything in one launch.  The SH degree-3 part needs ~180 VGPRs next to the geometry
+// (2 waves per SIMD: latency-bound), so the staged mode runs as two launches instead:
+// PART 1 = everything but the SH colours (126 VGPRs), PART 2 = the SH part alone, which adds its
+// share of d/d means3D to what PART 1 wrote.
+template <int DEG, int MODE, int PART>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, const float* __restrict__ means3D,
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float gop = 0.f;
     float gcol[3] = {0.f, 0.f, 0.f};
     constexpr int NB = (DEG + 1) * (DEG + 1);
-    float* gsh_out = (g_shs && in_range) ? g_shs + (size_t)i * K * 3 : nullptr;
+    float* gsh_out = (g_shs && in_range && PART != 1) ? g_shs + (size_t)i * K * 3 : nullptr;
     int sh_written = 0;
     // ---- staged SH rows of this wave's 64 Gaussians
     const int lane = threadIdx.x & 63;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int RL = 3 * K;
     const int i0 = i - lane;                      // first Gaussian of this wave
     const int nq = STAGE && i0 < N ? ((N - i0 < 64 ? N - i0 : 64) * RL) / 4 : 0;   // float4s in the chunk
-    if (STAGE && shs) {
+    if (STAGE && shs && PART != 1) {
         const uint64_t dmask = __ballot(drawn);
         const float4* p4 = reinterpret_cast<const float4*>(shs + (size_t)i0 * RL);
         for (int m = lane; m < nq; m += 64) {
@@ -338,9 +342,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     }
     if (drawn) {
         Geom g;
-        project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
-        const float4 r0 = grad_rows[4 * (size_t)i], r1 = grad_rows[4 * (size_t)i + 1],
-                     r2 = grad_rows[4 * (size_t)i + 2];
+        if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
+        const float4 r0 = PART != 2 ? grad_rows[4 * (size_t)i] : make_float4(0.f, 0.f, 0.f, 0.f),
+                     r1 = grad_rows[4 * (size_t)i + 1], r2 = grad_rows[4 * (size_t)i + 2];
         const float d_mx = r0.x, d_my = r0.y, d_a = r0.z, d_b = r0.w;
         const float d_d = r1.x, d_op = r1.y, d_r = r1.z, d_g = r1.w;
         const float d_bl = r2.x, d_z = r2.y;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         // ---- colour
         if (colors_precomp) {
             gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
-        } else if (shs) {
+        } else if (shs && PART != 1) {
             float b[NB], bg[NB][3];
             const float vx = px - campos[0], vy = py - campos[1], vz = pz - campos[2];
             const float n = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 gm[0] += ddir[0] / ne; gm[1] += ddir[1] / ne; gm[2] += ddir[2] / ne;
             }
         }
+        if (PART != 2) {
         // ---- screen mean
         {
             const float wden = g.clip[3] + 1e-7f;
@@ -518,8 +523,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             gq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + r * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
             gq[3] = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
         }
+        }   // PART != 2
     }
-    if (in_range) {
+    if (PART == 2) {
+        if (drawn && g_means3D) {   // add the SH part's share to what PART 1 wrote
+            g_means3D[3 * (size_t)i] += gm[0]; g_means3D[3 * (size_t)i + 1] += gm[1]; g_means3D[3 * (size_t)i + 2] += gm[2];
+        }
+    } else if (in_range) {
         if (g_means3D) { g_means3D[3 * (size_t)i] = gm[0]; g_means3D[3 * (size_t)i + 1] = gm[1]; g_means3D[3 * (size_t)i + 2] = gm[2]; }
         if (g_means2D) {
             // densification statistic: gradient w.r.t. the NDC-scaled screen mean (pixels * W/2, H/2)
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         if (g_colors) { g_colors[3 * (size_t)i] = gcol[0]; g_colors[3 * (size_t)i + 1] = gcol[1]; g_colors[3 * (size_t)i + 2] = gcol[2]; }
     }
     if (STAGE) {
-        if (g_shs) {   // wave-uniform
+        if (g_shs && PART != 1) {   // wave-uniform
             if (in_range)
                 for (int k = sh_written; k < RL; ++k) st_row[k] = 0.0f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -585,13 +595,16 @@ int launch_bwd(int mode, int N, int K, int H, int W, const float* view, const fl
                const float4* rows, float* g_means3D, float* g_means2D, float* g_scales, float* g_rots,
                float* g_cov6, float* g_opac, float* g_shs, float* g_colors, hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
-#define GS_LAUNCH_BWD(MODE)                                                                                      \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<DEG, MODE>), grid, block, 0, stream, N, K, H, W, view, proj, campos, \
-                       means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D, g_means2D, g_scales,    \
-                       g_rots, g_cov6, g_opac, g_shs, g_colors)
-    if (mode == 2) GS_LAUNCH_BWD(2);
-    else if (mode == 1) GS_LAUNCH_BWD(1);
-    else GS_LAUNCH_BWD(0);
+#define GS_LAUNCH_BWD(D_, MODE, PART)                                                                            \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<D_, MODE, PART>), grid, block, 0, stream, N, K, H, W, view, proj,     \
+                       campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D, g_means2D,        \
+                       g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors)
+    if (mode == 2) {
+        GS_LAUNCH_BWD(0, 0, 1);
+        GS_CHECK_LAUNCH("preprocess_bwd (geometry)");
+        GS_LAUNCH_BWD(DEG, 2, 2);
+    } else if (mode == 1) GS_LAUNCH_BWD(DEG, 1, 0);
+    else GS_LAUNCH_BWD(DEG, 0, 0);
 #undef GS_LAUNCH_BWD
     GS_CHECK_LAUNCH("preprocess_bwd");
     return GS_OK;

@@ -408,3 +408,34 @@ def test_config5_4k_forward_vs_oracle_and_bands(dgr, oracle):
     with torch.no_grad():
         bands = [par.render_band(settings, r, 8, **kw)[0] for r in range(8)]
     assert torch.equal(torch.cat(bands, dim=1), image.detach())
+
+
+def test_tile_row_bands_backward_adds_up(dgr):
+    """Bands partition the pixels, so the per-band gradients of (image * G).sum() add up to the full frame's."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+    sc = syn.make_scene(20000, 16, 203, 317, seed=8)
+    dev = torch.device("cuda:0")
+    settings = _scene_settings(dgr, sc, dev)
+    G = sc.G.to(dev)
+
+    def grads(world):
+        inp = {k: v.clone().requires_grad_(True) for k, v in _scene_inputs(sc, dev).items()}
+        kw = dict(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
+                  scales=inp["scales"], rotations=inp["rotations"])
+        if world == 1:
+            image = dgr.GaussianRasterizer(settings)(**kw)[0]
+            (image * G).sum().backward()
+        else:
+            for r in range(world):
+                img_band, _, _, (y0, y1) = par.render_band(settings, r, world, **kw)
+                if y1 > y0:
+                    (img_band * G[:, y0:y1]).sum().backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.cpu().numpy() for k, v in inp.items()}
+
+    full = grads(1)
+    for world in (2, 5):
+        banded = grads(world)
+        for k in full:
+            check_grad(f"bands{world}:d_{k}", banded[k], full[k], rel=2e-5)   # fp32 summation order only

@@ -209,12 +209,38 @@ def main():
                           "frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 4)},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         }
+        if world == 1 and not forward_only:
+            out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_loss(impl, H, W, dev, iters=20):
+    """SURVEY.md 8f row 1 (outside the headline metric): fused L1 + SSIM loss, value + d/d image, on one
+    (3,H,W) frame; HIP events around the call.  Algorithmic bytes: 8 read + 12 written (forward maps),
+    20 read + 4 written (backward) per pixel-channel."""
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(3, H, W, generator=g).to(dev)
+    img = (gt + 0.05 * torch.randn(3, H, W, generator=g).to(dev)).clamp(0, 1).requires_grad_(True)
+    for _ in range(3):
+        impl.l1_ssim_loss(img, gt, 0.2).backward()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        img.grad = None
+        impl.l1_ssim_loss(img, gt, 0.2).backward()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    nbytes = 44 * 3 * H * W
+    return {"ms_fwd_bwd": round(ms, 4), "algorithmic_bytes": nbytes,
+            "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4),
+            "note": "includes the autograd plumbing (two small torch kernels) around the three HIP launches"}
 
 
 def cpu_baseline(scene):

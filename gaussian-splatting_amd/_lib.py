@@ -28,6 +28,8 @@ PROTOTYPES = {
     "gs_sort_pairs": (_i, [_ll, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "gs_identify_tile_ranges": (_i, [_ll, _vp, _i, _vp, _vp, _vp]),
     "gs_render_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _sz, _vp]),
+    "gs_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
+    "gs_l1_ssim": (_i, [_i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "gs_render_bwd": (_i, [_i, _i] + [_vp] * 10 + [_f, _i, _i, _vp]),
 }
 

@@ -147,6 +147,19 @@ int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* vi
                       float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
                       float* g_colors_precomp, void* stream);
 
+/*
+ * Training loss, fused (the step right after the rasterizer in every iteration).
+ * Replaces l1_loss (utils/loss_utils.py:10-21), ssim / calculate_ssim / ssim_loss (:74-115, :118-140,
+ * :193-205; 11x11 window of sigma 1.5, :38-71) and their autograd as train.py:141-146 combines them.
+ * img, gt: (C,H,W) fp32.  loss_out (device, 3 floats) = (w_l1 * L1 + w_ssim * mean SSIM, L1, mean SSIM);
+ * grad (C,H,W, may be NULL) = d loss_out[0] / d img.  The reference's trainer uses w_l1 = 1 - lambda,
+ * w_ssim = +lambda (its "1 - ssim_loss(...)" is SSIM itself); pass w_ssim = -lambda for the D-SSIM of
+ * the 3DGS paper (the constant lambda is then missing from loss_out[0]).
+ */
+size_t gs_l1_ssim_workspace_bytes(int C, int H, int W);
+int gs_l1_ssim(int C, int H, int W, const float* img, const float* gt, float w_l1, float w_ssim, float* loss_out,
+               float* grad, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

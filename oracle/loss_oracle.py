@@ -26,7 +26,7 @@ C2 = 0.03 ** 2
 
 
 # The reference's window, float32, exactly as its gaussian(11, 1.5) returns it (utils/loss_utils.py:38-53;
-# recorded in tests/golden/loss_window_1d.npz).  The values matter to the last bit: they sum to
+# recorded in tests/golden/loss/_window_1d.npz).  The values matter to the last bit: they sum to
 # 1 - 3.1e-8, and because sigma = E[x^2] - mu^2 cancels, a window that sums to 1 + 1e-7 instead moves
 # the SSIM of a smooth image by 7e-6.
 WINDOW_1D_HEX = ("0x1.0d956cp-10", "0x1.f1fe02p-8", "0x1.26eb18p-5", "0x1.bff0fep-4", "0x1.b43c3ep-3", "0x1.10656p-2",

@@ -25,7 +25,7 @@ from utils.loss_utils import gaussian, l1_loss, ssim_loss  # noqa: E402  (the re
 
 torch.set_num_threads(8)
 # the reference's 1-D window, bit for bit (the kernels and the oracle embed these 11 floats)
-np.savez(os.path.join(HERE, "loss_window_1d.npz"), g=gaussian(11, 1.5).numpy())
+np.savez(os.path.join(HERE, "loss", "_window_1d.npz"), g=gaussian(11, 1.5).numpy())
 CASES = [  # name, C, H, W, seed, lambda, kind
     ("rand_3x37x53", 3, 37, 53, 0, 0.2, "rand"),
     ("smooth_3x64x64", 3, 64, 64, 1, 0.2, "smooth"),

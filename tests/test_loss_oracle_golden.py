@@ -8,7 +8,7 @@ import pytest
 
 from oracle import loss_oracle
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "loss", "*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "loss", "[a-z]*.npz")))
 
 # the reference's own float32 noise against its float64 run on these cases: 3.5e-7 (SSIM), 2e-4 of max|grad|
 TOL_LOSS = 1e-6          # absolute, loss values are O(0.1 .. 1)
@@ -29,5 +29,5 @@ def test_loss_oracle_matches_reference(path):
 
 def test_window_is_the_references_bit_for_bit():
     w = loss_oracle.window_1d()
-    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_window_1d.npz"))["g"]
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss", "_window_1d.npz"))["g"]
     assert w.dtype == np.float32 and np.array_equal(w, ref) and np.array_equal(w, w[::-1])

@@ -122,3 +122,192 @@ def gather_bands(band: torch.Tensor, H: int, dst: int = 0, group: Optional[dist.
     if rank != dst:
         return None
     return torch.cat([parts[r][:, :spans[r][1] - spans[r][0]] for r in range(world)], dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Gaussian-sharded training step: exchange splat records, not gradients
+# ---------------------------------------------------------------------------------------------------
+def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows, in_rows, group):
+    """all_to_all_single along dim 0 with per-peer row counts.  RCCL (and gloo on CPU tensors) take it
+    directly; gloo has no device all-to-all, so device tensors are staged through the host there (that
+    combination only exists in tests: two ranks on one GPU)."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), list(out_rows), list(in_rows), group=group)
+        out.copy_(o)
+        return
+    dist.all_to_all_single(out, inp, list(out_rows), list(in_rows), group=group)
+
+
+class _RasterizeSharded(torch.autograd.Function):
+    """One training step over `world` views with the Gaussians sharded over ranks (see SplatExchange)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                views, t_eps, counts, group):
+        from . import rasterizer as R
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = means3D.device
+        n = means3D.shape[0]
+        total = int(sum(counts))
+        mine = views[rank]
+        i32 = dict(dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            # 1. project my shard into every rank's view, straight into the send buffers
+            splat_s = torch.empty((world, max(n, 1), 12), dtype=torch.float32, device=dev)[:, :n]
+            dkeys_s = torch.empty((world, max(n, 1)), **i32)[:, :n]
+            rects_s = torch.empty((world, max(n, 1), 2), **i32)[:, :n]
+            ids_scratch = torch.empty((max(n, 1),), **i32)[:n]
+            radii = []
+            for v in range(world):
+                _, r, _, _, _, _ = R.preprocess(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                                colors_precomp, out=(splat_s[v], dkeys_s[v], ids_scratch, rects_s[v]))
+                radii.append(r)
+            radii = torch.stack(radii) if world else torch.empty((0, n), **i32)
+            # 2. records, depth keys and boxes of ALL Gaussians for MY view, in global index order
+            splat = torch.empty((max(total, 1), 12), dtype=torch.float32, device=dev)[:total]
+            dkeys = torch.empty((2, max(total, 1)), **i32)
+            ids = torch.empty((2, max(total, 1)), **i32)
+            rects = torch.empty((max(total, 1), 2), **i32)[:total]
+            same = [n] * world
+            _all_to_all_rows(splat, splat_s.reshape(world * n, 12), counts, same, group)
+            _all_to_all_rows(dkeys[0][:total], dkeys_s.reshape(world * n), counts, same, group)
+            _all_to_all_rows(rects, rects_s.reshape(world * n, 2), counts, same, group)
+            torch.arange(total, out=ids[0][:total], **i32)
+            # 3. bin and composite my view
+            state = R.bin_splats(mine, splat, None, None, dkeys, ids, rects)
+            need_grad = any(t is not None and t.requires_grad for t in
+                            (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
+            band = R._band(mine, None)
+            image, depth, alpha, aux, rows = R.render_forward(mine, splat, state.ranges, state.point_list, need_grad,
+                                                              t_eps, band)
+        ctx.rows = rows
+        ctx.set_materialize_grads(False)
+        ctx.views, ctx.t_eps, ctx.counts, ctx.group, ctx.band = views, float(t_eps), list(counts), group, band
+        ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
+        ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
+        saved = [means3D, opacities, splat, radii, state.point_list, state.ranges, depth, alpha]
+        saved += [t for t in (shs, colors_precomp, scales, rotations, cov3D_precomp) if t is not None]
+        if aux is not None:
+            saved.append(aux)
+        ctx.has_aux = aux is not None
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(radii)
+        return image, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_image, g_radii, g_depth, g_alpha):
+        from . import rasterizer as R
+        saved = list(ctx.saved_tensors)
+        means3D, opacities, splat, radii, point_list, ranges, depth, alpha = saved[:8]
+        rest = saved[8:]
+        opt = [rest.pop(0) if h else None for h in ctx.has]
+        shs, colors_precomp, scales, rotations, cov3D_precomp = opt
+        if not ctx.has_aux:
+            raise RuntimeError("backward called but no input required grad in forward")
+        aux = rest.pop(0)
+        group, views, counts = ctx.group, ctx.views, ctx.counts
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = means3D.device
+        n = means3D.shape[0]
+        needs = list(ctx.needs_input_grad[:8])
+        per_view_means2D = ctx.means2D_shape == (world, n, 3)
+        with torch.cuda.device(dev):
+            rows, ctx.rows = ctx.rows, None
+            rows = R.render_backward(views[rank], splat, ranges, point_list, aux, depth, alpha, g_image, g_depth,
+                                     g_alpha, rows, ctx.t_eps, ctx.band)
+            total = int(sum(counts))
+            # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, 16)
+            rows_mine = torch.empty((world * max(n, 1), R.GRAD_ROW), dtype=torch.float32, device=dev)[:world * n]
+            _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group)
+            rows_mine = rows_mine.view(world, n, R.GRAD_ROW)
+            # 5. chain rule through my shard's projection into each view, summed over the views
+            acc = [None] * 8
+            g_m2d = []
+            pv_needs = list(needs)
+            for v in range(world):
+                g = R.preprocess_backward(views[v], means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
+                                          radii[v], rows_mine[v], pv_needs, (n, 3) if per_view_means2D else None)
+                if per_view_means2D and needs[1]:
+                    g_m2d.append(g[1])
+                for k in (0, 2, 3, 4, 5, 6, 7):
+                    if g[k] is not None:
+                        acc[k] = g[k] if acc[k] is None else acc[k].add_(g[k])
+            if needs[1] and ctx.means2D_shape is not None:
+                acc[1] = torch.stack(g_m2d) if per_view_means2D else \
+                    torch.zeros(ctx.means2D_shape, dtype=torch.float32, device=dev)
+        return (*acc, None, None, None, None)
+
+
+class SplatExchange:
+    """Training step for `world` ranks that each OWN a contiguous shard of the Gaussians (rank r holds
+    global indices [sum(counts[:r]), sum(counts[:r+1]))) and each RENDER one view per step.
+
+    No counterpart in the reference (single GPU, one view per iteration, train.py:129-135).  Instead of
+    replicating the Gaussians and all-reducing 59 floats per Gaussian (GradReducer: 236 B x N through
+    ring steps), the ranks exchange what the per-tile kernels actually consume and produce:
+
+      forward   rank r projects its shard into every rank's view (gs_preprocess_fwd, `world` launches on
+                N/world Gaussians each) and one all-to-all hands every renderer the 48-byte splat records,
+                depth keys and boxes of all N Gaussians for its view (60 B per Gaussian and view);
+      backward  the renderer's 64-byte gradient rows (the ten per-Gaussian sums of render_bwd) go back to
+                the owners in one all-to-all, and each owner runs gs_preprocess_bwd per view on its shard.
+
+    124 B per Gaussian and view, all of it direct peer-to-peer traffic -- the pattern the fully connected
+    xGMI mesh is built for -- and parameters, gradients and optimizer state stay sharded (no replica,
+    no parameter broadcast).  The image each rank gets is bit-identical to a single-GPU render of the
+    concatenated Gaussians; the gradients equal the sum over the views of the single-GPU gradients.
+
+    `means2D` (optional) has shape (world, n_local, 3): its gradient is the per-view screen-space
+    gradient of the local Gaussians, so add_densification_stats (scene/gaussian_model.py:701-713) and
+    max_radii2D need no collective at all (`radii` is returned per view: (world, n_local)).
+    """
+
+    def __init__(self, n_local: int, device=None, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.set_local_count(n_local, device)
+
+    def set_local_count(self, n_local: int, device=None):
+        """(Re)publish the shard sizes; call again after densification / pruning changed n_local."""
+        world = dist.get_world_size(self.group)
+        use_dev = dist.get_backend(self.group) != "gloo"
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=device if use_dev else None)
+        allc = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allc, t, group=self.group)
+        self.counts = [int(c.item()) for c in allc]
+        self.n_local = int(n_local)
+
+    @property
+    def offset(self) -> int:
+        return sum(self.counts[:dist.get_rank(self.group)])
+
+    def rasterize(self, views, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
+                  rotations=None, cov3D_precomp=None, t_eps=None):
+        """views: one GaussianRasterizationSettings per rank (views[r] is rendered by rank r; every rank
+        passes the same list).  The other arguments are this rank's shard, as for GaussianRasterizer.
+        Returns (image of views[rank], radii (world, n_local), depth, alpha)."""
+        from . import rasterizer as R
+        world = dist.get_world_size(self.group)
+        if len(views) != world:
+            raise ValueError(f"need one view per rank ({world}), got {len(views)}")
+        if (shs is None) == (colors_precomp is None):
+            raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if opacities is None:
+            raise ValueError("opacities is required")
+        n = means3D.shape[0]
+        if n != self.n_local:
+            raise ValueError(f"shard has {n} Gaussians, {self.n_local} were published (call set_local_count)")
+        dev = means3D.device
+        means3D = R._prep(means3D, "means3D", (3,), dev)
+        shs = R._prep(shs, "shs", None, dev)
+        colors_precomp = R._prep(colors_precomp, "colors_precomp", (3,), dev)
+        opacities = R._prep(opacities.reshape(n, 1) if opacities.dim() == 1 else opacities, "opacities", (1,), dev)
+        scales = R._prep(scales, "scales", (3,), dev)
+        rotations = R._prep(rotations, "rotations", (4,), dev)
+        cov3D_precomp = R._prep(cov3D_precomp, "cov3D_precomp", (6,), dev)
+        return _RasterizeSharded.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, list(views), R.DEFAULT_T_EPS if t_eps is None else t_eps,
+                                       list(self.counts), self.group)

@@ -116,9 +116,11 @@ def _band(settings, tile_rows):
     return b, e
 
 
-def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
-                       cov3D_precomp, shs, colors_precomp, tile_rows=None) -> BinningState:
-    """preprocess -> depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges (current stream)."""
+def preprocess(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
+               colors_precomp, tile_rows=None, out=None):
+    """gs_preprocess_fwd on the current stream.  Returns (splat (N,12), radii, tiles_touched, dkeys (N,),
+    ids (N,), rects (N,2)).  `out` = preallocated contiguous (splat, dkeys, ids, rects) to write into
+    (rows of the sort's ping-pong buffers, or slices of an exchange buffer: parallel.SplatExchange)."""
     lib = _lib.load()
     dev = means3D.device
     N = means3D.shape[0]
@@ -127,22 +129,52 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     view = _camera_tensor(settings.viewmatrix, 16, "viewmatrix", dev)
     proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
     campos = _camera_tensor(settings.campos, 3, "campos", dev)
-    st = _stream()
     row_b, row_e = _band(settings, tile_rows)
     i32 = dict(dtype=torch.int32, device=dev)
-    splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
+    if out is None:
+        out = (torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N], torch.empty((max(N, 1),), **i32)[:N],
+               torch.empty((max(N, 1),), **i32)[:N], torch.empty((max(N, 1), 2), **i32)[:N])
+    splat, dkeys, ids, rects = out
+    if (tuple(splat.shape), tuple(dkeys.shape), tuple(ids.shape), tuple(rects.shape)) != ((N, 12), (N,), (N,), (N, 2)) \
+            or not all(t.is_contiguous() for t in out):
+        raise ValueError("preprocess: output buffers must be contiguous (N,12), (N,), (N,), (N,2)")
     radii = torch.empty((N,), **i32)
     tiles_touched = torch.empty((N,), **i32)
-    # depth keys / Gaussian ids, ping-pong buffers of the per-Gaussian depth sort
-    dkeys = torch.empty((2, max(N, 1)), **i32)
-    ids = torch.empty((2, max(N, 1)), **i32)
-    rects = torch.empty((max(N, 1), 2), **i32)
     with _stage("preprocess_fwd"):
         _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
-                                         _ptr(radii), _ptr(tiles_touched), _ptr(dkeys[0]), _ptr(ids[0]),
-                                         _ptr(rects), row_b, row_e, st), "gs_preprocess_fwd")
+                                         _ptr(radii), _ptr(tiles_touched), _ptr(dkeys), _ptr(ids),
+                                         _ptr(rects), row_b, row_e, _stream()), "gs_preprocess_fwd")
+    return splat, radii, tiles_touched, dkeys, ids, rects
+
+
+def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
+                       cov3D_precomp, shs, colors_precomp, tile_rows=None) -> BinningState:
+    """preprocess -> depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges (current stream)."""
+    dev = means3D.device
+    N = means3D.shape[0]
+    i32 = dict(dtype=torch.int32, device=dev)
+    # depth keys / Gaussian ids: ping-pong buffers of the per-Gaussian depth sort, input in row 0
+    dkeys = torch.empty((2, max(N, 1)), **i32)
+    ids = torch.empty((2, max(N, 1)), **i32)
+    splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
+    rects = torch.empty((max(N, 1), 2), **i32)[:N]
+    _, radii, tiles_touched, _, _, _ = preprocess(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                                  colors_precomp, tile_rows, out=(splat, dkeys[0][:N], ids[0][:N], rects))
+    return bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows)
+
+
+def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows=None) -> BinningState:
+    """depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges for N preprocessed Gaussians.
+    dkeys / ids: (2,N) ping-pong buffers with the sort input in row 0; rects: (N,2)."""
+    lib = _lib.load()
+    dev = splat.device
+    N = splat.shape[0]
+    H, W = settings.image_height, settings.image_width
+    st = _stream()
+    row_b, row_e = _band(settings, tile_rows)
+    i32 = dict(dtype=torch.int32, device=dev)
     in_b = C.c_int(0)
     ws_bytes = lib.gs_sort_workspace_bytes(N)
     sort_ws = torch.empty((max(16, ws_bytes),), dtype=torch.uint8, device=dev)
@@ -231,37 +263,105 @@ def _readback_slot(dev):
     return slot
 
 
+def render_forward(settings, splat, ranges, point_list, need_grad, t_eps, band):
+    """gs_render_fwd on the current stream -> (image, depth, alpha, aux, rows); aux / rows (the backward's
+    per-Gaussian gradient rows, cleared by the VALU-bound forward kernel for free) only if need_grad."""
+    lib = _lib.load()
+    dev = splat.device
+    N = splat.shape[0]
+    H, W = settings.image_height, settings.image_width
+    bg = _camera_tensor(settings.bg, 3, "bg", dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    image = torch.empty((3, H, W), **f32)
+    depth = torch.empty((1, H, W), **f32)
+    alpha = torch.empty((1, H, W), **f32)
+    aux = torch.empty((3, H, W), **f32) if need_grad else None
+    rows = torch.empty((max(N, 1), GRAD_ROW), **f32) if need_grad else None
+    with _stage("render_fwd"):
+        _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(image),
+                                     _ptr(depth), _ptr(alpha), _ptr(aux), float(t_eps), band[0], band[1], _ptr(rows),
+                                     rows.numel() * 4 if rows is not None else 0, _stream()), "gs_render_fwd")
+    return image, depth, alpha, aux, rows
+
+
+def render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_image, g_depth, g_alpha, rows, t_eps, band):
+    """gs_render_bwd on the current stream: adds this frame's per-Gaussian sums into `rows` ((N,16), zeroed
+    by the forward; None = allocate zeros) and returns it."""
+    lib = _lib.load()
+    dev = splat.device
+    N = splat.shape[0]
+    H, W = settings.image_height, settings.image_width
+
+    def gin(t, shape):
+        if t is None:
+            return None
+        return t.to(torch.float32).expand(shape).contiguous()
+
+    g_image = gin(g_image, (3, H, W))
+    if g_image is None:
+        g_image = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    g_depth = gin(g_depth, (1, H, W))
+    g_alpha = gin(g_alpha, (1, H, W))
+    if rows is None:
+        rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
+    with _stage("render_bwd"):
+        _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux), _ptr(depth),
+                                     _ptr(alpha), _ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(rows), float(t_eps),
+                                     band[0], band[1], _stream()), "gs_render_bwd")
+    return rows
+
+
+def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows,
+                        needs, means2D_shape):
+    """gs_preprocess_bwd on the current stream.  `needs` = 8 flags in the order of GaussianRasterizer.forward's
+    arguments; returns the 8 gradients (None where not needed)."""
+    lib = _lib.load()
+    dev = means3D.device
+    N = means3D.shape[0]
+    H, W = settings.image_height, settings.image_width
+    K = shs.shape[1] if shs is not None else 0
+    view = _camera_tensor(settings.viewmatrix, 16, "viewmatrix", dev)
+    proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
+    campos = _camera_tensor(settings.campos, 3, "campos", dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
+    g_means2D = torch.empty(means2D_shape, **f32) if (needs[1] and means2D_shape == (N, 3)) else None
+    g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
+    g_colors = torch.empty((N, 3), **f32) if (colors_precomp is not None and needs[3]) else None
+    g_opac = torch.empty((N, 1), **f32) if needs[4] else None
+    g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
+    g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
+    g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
+    with _stage("preprocess_bwd"):
+        _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
+                                         _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
+                                         _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
+                                         _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
+                                         _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors), _stream()),
+                   "gs_preprocess_bwd")
+    if needs[1] and g_means2D is None and means2D_shape is not None:
+        g_means2D = torch.zeros(means2D_shape, **f32)
+    return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                 settings, t_eps, tile_rows=None):
-        lib = _lib.load()
         dev = means3D.device
-        H, W = settings.image_height, settings.image_width
-        bg = _camera_tensor(settings.bg, 3, "bg", dev)
         with torch.cuda.device(dev):
-            row_b, row_e = _band(settings, tile_rows)
+            band = _band(settings, tile_rows)
             state = preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
                                        colors_precomp, tile_rows)
             need_grad = any(t is not None and t.requires_grad for t in
                             (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
-            image = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-            depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            aux = torch.empty((3, H, W), dtype=torch.float32, device=dev) if need_grad else None
-            # the backward's per-Gaussian gradient rows: cleared by the (VALU-bound) forward kernel for free
-            N = means3D.shape[0]
-            rows = torch.empty((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev) if need_grad else None
-            with _stage("render_fwd"):
-                _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(state.splat), _ptr(state.ranges),
-                                             _ptr(state.point_list), _ptr(image), _ptr(depth), _ptr(alpha),
-                                             _ptr(aux), float(t_eps), row_b, row_e, _ptr(rows),
-                                             rows.numel() * 4 if rows is not None else 0, _stream()), "gs_render_fwd")
+            image, depth, alpha, aux, rows = render_forward(settings, state.splat, state.ranges, state.point_list,
+                                                            need_grad, t_eps, band)
         ctx.rows = rows
         ctx.set_materialize_grads(False)   # unused outputs (depth, alpha) arrive as None, not as zero fills
         ctx.settings = settings
         ctx.t_eps = float(t_eps)
-        ctx.band = (row_b, row_e)
+        ctx.band = band
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         saved = [means3D, opacities, state.splat, state.radii, state.point_list, state.ranges, depth, alpha]
@@ -275,7 +375,6 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_image, g_radii, g_depth, g_alpha):
-        lib = _lib.load()
         saved = list(ctx.saved_tensors)
         means3D, opacities, splat, radii, point_list, ranges, depth, alpha = saved[:8]
         rest = saved[8:]
@@ -287,54 +386,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("backward called but no input required grad in forward")
         aux = rest.pop(0)
         settings = ctx.settings
-        dev = means3D.device
-        N = means3D.shape[0]
-        H, W = settings.image_height, settings.image_width
-        K = shs.shape[1] if shs is not None else 0
-        view = _camera_tensor(settings.viewmatrix, 16, "viewmatrix", dev)
-        proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
-        campos = _camera_tensor(settings.campos, 3, "campos", dev)
-
-        def gin(t, shape):
-            if t is None:
-                return None
-            return t.to(torch.float32).expand(shape).contiguous()
-
-        with torch.cuda.device(dev):
-            st = _stream()
-            g_image = gin(g_image, (3, H, W))
-            if g_image is None:
-                g_image = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-            g_depth = gin(g_depth, (1, H, W))
-            g_alpha = gin(g_alpha, (1, H, W))
+        with torch.cuda.device(means3D.device):
             rows, ctx.rows = ctx.rows, None          # cleared by the forward; a second backward clears its own
-            if rows is None:
-                rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
-            with _stage("render_bwd"):
-                _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux),
-                                             _ptr(depth), _ptr(alpha), _ptr(g_image), _ptr(g_depth),
-                                             _ptr(g_alpha), _ptr(rows), ctx.t_eps, ctx.band[0], ctx.band[1], st),
-                           "gs_render_bwd")
-            needs = ctx.needs_input_grad
-            f32 = dict(dtype=torch.float32, device=dev)
-            g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
-            g_means2D = torch.empty(ctx.means2D_shape, **f32) if (needs[1] and ctx.means2D_shape == (N, 3)) else None
-            g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
-            g_colors = torch.empty((N, 3), **f32) if (colors_precomp is not None and needs[3]) else None
-            g_opac = torch.empty_like(opacities) if needs[4] else None
-            g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
-            g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
-            g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
-            with _stage("preprocess_bwd"):
-                _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
-                                                 _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                                 _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
-                                                 _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
-                                                 _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors), st),
-                           "gs_preprocess_bwd")
-        if needs[1] and g_means2D is None and ctx.means2D_shape is not None:
-            g_means2D = torch.zeros(ctx.means2D_shape, **f32)
-        return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov, None, None, None
+            rows = render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_image, g_depth, g_alpha,
+                                   rows, ctx.t_eps, ctx.band)
+            grads = preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
+                                        radii, rows, ctx.needs_input_grad, ctx.means2D_shape)
+        return (*grads, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,

@@ -5,6 +5,8 @@
    all-reduce sums the per-Gaussian gradients; result == sequential accumulation of the same views.
  * densification statistics: SUM / SUM / MAX.
  * tile-row sharded frame: bands gathered on rank 0 == the whole frame.
+ * Gaussian-sharded step (SplatExchange): shard bookkeeping and the uneven all-to-all both ways (the
+   kernels around it need a GPU: tests/test_gpu_exchange.py).
 """
 import importlib
 import os
@@ -78,6 +80,20 @@ def _worker(rank, world, port, tmp):
             assert torch.equal(full, frame)
         else:
             assert full is None
+        # ---- splat exchange plumbing: shard sizes, offsets, uneven all-to-all in global index order
+        counts = [3, 5]
+        ex = par.SplatExchange(counts[rank])
+        assert ex.counts == counts and ex.offset == sum(counts[:rank])
+        n = counts[rank]
+        # row (v, i) of my send buffer = "Gaussian offset+i seen from view v"
+        send = torch.stack([torch.arange(ex.offset, ex.offset + n, dtype=torch.float32) + 100.0 * v
+                            for v in range(world)]).reshape(world * n, 1)
+        recv = torch.empty((sum(counts), 1))
+        par._all_to_all_rows(recv, send, counts, [n] * world, None)
+        assert torch.equal(recv[:, 0], torch.arange(8, dtype=torch.float32) + 100.0 * rank)
+        back = torch.empty((world * n, 1))
+        par._all_to_all_rows(back, recv, [n] * world, counts, None)     # the backward's direction
+        assert torch.equal(back, send)
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

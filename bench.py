@@ -69,6 +69,11 @@ def main():
     ap.add_argument("--t-eps", type=float, default=None, help="per-pixel stop threshold (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--parallel", default="exchange", choices=["exchange", "allreduce"],
+                    help="N > 1: 'exchange' = Gaussians sharded, splat records / gradient rows exchanged "
+                         "(parallel.SplatExchange); 'allreduce' = Gaussians replicated, gradients all-reduced")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path (process group, collectives) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,10 +87,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist  # noqa: PLW0621
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import diff_gaussian_rasterization as dgr
     impl = importlib.import_module("gaussian-splatting_amd")
@@ -96,18 +103,30 @@ def main():
     N, K, H, W = CONFIGS[args.config]
     t_eps = impl.DEFAULT_T_EPS if args.t_eps is None else args.t_eps
     scene = syn.make_scene(N, K, H, W, seed=0)
-    view = syn.jitter_view(scene, rank) if world > 1 else scene
-    params = {k: getattr(scene, k).to(dev).requires_grad_(True)
-              for k in ("means3D", "shs", "opacities", "scales", "rotations")}
-    G = scene.G.to(dev)
-    settings = dgr.GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=view.tanfovx, tanfovy=view.tanfovy, bg=view.bg.to(dev),
-        scale_modifier=1.0, viewmatrix=view.viewmatrix.to(dev), projmatrix=view.projmatrix.to(dev),
-        sh_degree=view.sh_degree, campos=view.campos.to(dev), prefiltered=False, debug=False)
-    rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
-    reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20)) if world > 1 else None
-
     forward_only = "forward_only" in args.config
+    exchange = multi and args.parallel == "exchange" and not forward_only
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def make_settings(view):
+        return dgr.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=view.tanfovx, tanfovy=view.tanfovy, bg=view.bg.to(dev),
+            scale_modifier=1.0, viewmatrix=view.viewmatrix.to(dev), projmatrix=view.projmatrix.to(dev),
+            sh_degree=view.sh_degree, campos=view.campos.to(dev), prefiltered=False, debug=False)
+
+    # N > 1: rank r renders view r of the SAME scene (camera jittered per view), one view per rank and step
+    views = [syn.jitter_view(scene, r) if multi else scene for r in range(world)]
+    settings = make_settings(views[rank])
+    if exchange:      # this rank owns Gaussians [lo, hi)
+        lo, hi = par.tile_row_band(N, rank, world)
+        params = {k: getattr(scene, k)[lo:hi].to(dev).requires_grad_(True) for k in names}
+        all_settings = [make_settings(v) for v in views]
+        ex = par.SplatExchange(hi - lo, device=dev)
+    else:
+        params = {k: getattr(scene, k).to(dev).requires_grad_(True) for k in names}
+    G = scene.G.to(dev)
+    rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
+    reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20)) \
+        if (multi and not exchange) else None
 
     def step():
         if forward_only:
@@ -117,6 +136,14 @@ def main():
                             rotations=params["rotations"], cov3D_precomp=None)[1]
         for p in params.values():
             p.grad = None
+        if exchange:
+            means2D = torch.zeros((world, params["means3D"].shape[0], 3), device=dev, requires_grad=True)
+            image, radii, depth, alpha = ex.rasterize(all_settings, params["means3D"], means2D=means2D,
+                                                      shs=params["shs"], opacities=params["opacities"],
+                                                      scales=params["scales"], rotations=params["rotations"],
+                                                      t_eps=t_eps)
+            image.backward(G)
+            return radii
         means2D = torch.zeros_like(params["means3D"], requires_grad=True)
         image, radii, depth, alpha = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
                                           colors_precomp=None, opacities=params["opacities"],
@@ -162,9 +189,10 @@ def main():
     if rank == 0:
         # workload statistics for the byte model
         with torch.no_grad():
-            st = impl.preprocess_and_bin(settings, *[params[k].detach() for k in
-                                                     ("means3D", "opacities", "scales", "rotations")],
-                                         None, params["shs"].detach(), None)
+            full = {k: getattr(scene, k).to(dev) for k in names} if exchange else \
+                {k: params[k].detach() for k in names}
+            st = impl.preprocess_and_bin(settings, full["means3D"], full["opacities"], full["scales"],
+                                         full["rotations"], None, full["shs"], None)
             V = int((st.radii > 0).sum().item())
             D = st.num_pairs
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -203,7 +231,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.config, "gaussians": N, "sh_coeffs": K, "width": W, "height": H,
                        "drawn": V, "tile_pairs": D, "t_eps": t_eps,
-                       "views_per_step": world, "parallelism": f"views{world}" if world > 1 else "single"},
+                       "views_per_step": world,
+                       "parallelism": "single" if not multi else
+                       (f"views{world}+gaussians_sharded{world}(splat exchange)" if exchange else
+                        f"views{world}+gaussians_replicated(grad all-reduce)")},
             "roofline": roofline,
             "frame_hbm": {"algorithmic_bytes_v1": frame_bytes,
                           "frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 4)},

@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const float4* __restrict__ grad_rows, float* __restrict__ g_means3D,
     float* __restrict__ g_means2D, float* __restrict__ g_scales, float* __restrict__ g_rots,
     float* __restrict__ g_cov6, float* __restrict__ g_opac, float* __restrict__ g_shs,
-    float* __restrict__ g_colors) {
+    float* __restrict__ g_colors, bool acc) {
+    // acc: add this view's gradients to what the outputs hold (drawn Gaussians only; g_means2D, a
+    // per-view statistic, is always overwritten) instead of overwriting them
     constexpr bool VEC4 = MODE >= 1;
     constexpr bool STAGE = MODE == 2;
     __shared__ float stage_all[STAGE ? 4 * 64 * BWD_STAGE_STRIDE : 1];
@@ -417,17 +419,17 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                         float t[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) t[e] = b[(4 * v + e) / 3] * gcl[(4 * v + e) % 3];
+                        if (acc) {
+                            const float4 o = o4[v];
+                            t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
+                        }
                         o4[v] = make_float4(t[0], t[1], t[2], t[3]);
                     }
 #pragma unroll
-                    for (int f = 4 * NV; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3];
+                    for (int f = 4 * NV; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3] + (acc ? gsh_out[f] : 0.0f);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        gsh_out[3 * k + 0] = b[k] * gcl[0];
-                        gsh_out[3 * k + 1] = b[k] * gcl[1];
-                        gsh_out[3 * k + 2] = b[k] * gcl[2];
-                    }
+                    for (int f = 0; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3] + (acc ? gsh_out[f] : 0.0f);
                 }
                 sh_written = NB * 3;
             }
@@ -529,6 +531,27 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         if (drawn && g_means3D) {   // add the SH part's share to what PART 1 wrote
             g_means3D[3 * (size_t)i] += gm[0]; g_means3D[3 * (size_t)i + 1] += gm[1]; g_means3D[3 * (size_t)i + 2] += gm[2];
         }
+    } else if (in_range && acc) {
+        if (g_means2D) {
+            g_means2D[3 * (size_t)i] = gm2[0] * 0.5f * (float)W;
+            g_means2D[3 * (size_t)i + 1] = gm2[1] * 0.5f * (float)H;
+            g_means2D[3 * (size_t)i + 2] = 0.0f;
+        }
+        if (drawn) {
+            if (g_means3D) { g_means3D[3 * (size_t)i] += gm[0]; g_means3D[3 * (size_t)i + 1] += gm[1]; g_means3D[3 * (size_t)i + 2] += gm[2]; }
+            if (g_scales) { g_scales[3 * (size_t)i] += gs[0]; g_scales[3 * (size_t)i + 1] += gs[1]; g_scales[3 * (size_t)i + 2] += gs[2]; }
+            if (g_rots) {
+                float4* o = reinterpret_cast<float4*>(g_rots + 4 * (size_t)i);
+                const float4 t = *o;
+                *o = make_float4(t.x + gq[0], t.y + gq[1], t.z + gq[2], t.w + gq[3]);
+            }
+            if (g_cov6) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) g_cov6[6 * (size_t)i + k] += gc6[k];
+            }
+            if (g_opac) g_opac[i] += gop;
+            if (g_colors) { g_colors[3 * (size_t)i] += gcol[0]; g_colors[3 * (size_t)i + 1] += gcol[1]; g_colors[3 * (size_t)i + 2] += gcol[2]; }
+        }
     } else if (in_range) {
         if (g_means3D) { g_means3D[3 * (size_t)i] = gm[0]; g_means3D[3 * (size_t)i + 1] = gm[1]; g_means3D[3 * (size_t)i + 2] = gm[2]; }
         if (g_means2D) {
@@ -553,15 +576,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             float4* q4 = reinterpret_cast<float4*>(g_shs + (size_t)i0 * RL);
+            const uint64_t dmask = __ballot(drawn);
             for (int m = lane; m < nq; m += 64) {
                 const unsigned f = 4u * (unsigned)m, gi = f / (unsigned)RL, off = f - gi * (unsigned)RL;
                 const float* d = st_wave + gi * BWD_STAGE_STRIDE + off;
                 typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v o = {d[0], d[1], d[2], d[3]};
+                f4v o = {d[0], d[1], d[2], d[3]};
+                if (acc) {    // rows of culled Gaussians stay as they are
+                    if (!((dmask >> gi) & 1ull)) continue;
+                    const float4 t = q4[m];
+                    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+                }
                 __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(q4) + m);   // written once, read by the optimizer later
             }
         }
-    } else if (gsh_out) {
+    } else if (gsh_out && !acc) {
         int k = sh_written;
         if (VEC4 && (k & 3) == 0) {
             float4* o4 = reinterpret_cast<float4*>(gsh_out);
@@ -593,12 +622,12 @@ int launch_bwd(int mode, int N, int K, int H, int W, const float* view, const fl
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* shs, const float* colors, const int32_t* radii,
                const float4* rows, float* g_means3D, float* g_means2D, float* g_scales, float* g_rots,
-               float* g_cov6, float* g_opac, float* g_shs, float* g_colors, hipStream_t stream) {
+               float* g_cov6, float* g_opac, float* g_shs, float* g_colors, bool acc, hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
 #define GS_LAUNCH_BWD(D_, MODE, PART)                                                                            \
     hipLaunchKernelGGL((preprocess_bwd_kernel<D_, MODE, PART>), grid, block, 0, stream, N, K, H, W, view, proj,     \
                        campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D, g_means2D,        \
-                       g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors)
+                       g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors, acc)
     if (mode == 2) {
         GS_LAUNCH_BWD(0, 0, 1);
         GS_CHECK_LAUNCH("preprocess_bwd (geometry)");
@@ -661,7 +690,7 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
                                  const float* shs, const float* colors_precomp, const int32_t* radii,
                                  const float* grad_rows, float* g_means3D, float* g_means2D,
                                  float* g_scales, float* g_rotations, float* g_cov3D, float* g_opacities,
-                                 float* g_shs, float* g_colors, void* stream_) {
+                                 float* g_shs, float* g_colors, int accumulate, void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
@@ -676,9 +705,9 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
     const int deg = shs ? sh_degree : 0;
     const float4* rows = (const float4*)grad_rows;
     switch (deg) {
-        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
-        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
-        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
-        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, stream);
+        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
     }
 }

@@ -16,6 +16,8 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
+from .profiling import stage as _stage
+
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:
     """Views rendered by `rank`: r, r + world, ...."""
@@ -170,9 +172,10 @@ class _RasterizeSharded(torch.autograd.Function):
             ids = torch.empty((2, max(total, 1)), **i32)
             rects = torch.empty((max(total, 1), 2), **i32)[:total]
             same = [n] * world
-            _all_to_all_rows(splat, splat_s.reshape(world * n, 12), counts, same, group)
-            _all_to_all_rows(dkeys[0][:total], dkeys_s.reshape(world * n), counts, same, group)
-            _all_to_all_rows(rects, rects_s.reshape(world * n, 2), counts, same, group)
+            with _stage("exchange_fwd"):
+                _all_to_all_rows(splat, splat_s.reshape(world * n, 12), counts, same, group)
+                _all_to_all_rows(dkeys[0][:total], dkeys_s.reshape(world * n), counts, same, group)
+                _all_to_all_rows(rects, rects_s.reshape(world * n, 2), counts, same, group)
             torch.arange(total, out=ids[0][:total], **i32)
             # 3. bin and composite my view
             state = R.bin_splats(mine, splat, None, None, dkeys, ids, rects)
@@ -219,20 +222,20 @@ class _RasterizeSharded(torch.autograd.Function):
             total = int(sum(counts))
             # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, 16)
             rows_mine = torch.empty((world * max(n, 1), R.GRAD_ROW), dtype=torch.float32, device=dev)[:world * n]
-            _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group)
+            with _stage("exchange_bwd"):
+                _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group)
             rows_mine = rows_mine.view(world, n, R.GRAD_ROW)
             # 5. chain rule through my shard's projection into each view, summed over the views
-            acc = [None] * 8
+            acc = None
             g_m2d = []
-            pv_needs = list(needs)
-            for v in range(world):
+            for v in range(world):       # view 0 writes, the others add in place (accumulate flag of the C-ABI)
                 g = R.preprocess_backward(views[v], means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
-                                          radii[v], rows_mine[v], pv_needs, (n, 3) if per_view_means2D else None)
+                                          radii[v], rows_mine[v], needs, (n, 3) if per_view_means2D else None,
+                                          accumulate_into=acc)
                 if per_view_means2D and needs[1]:
                     g_m2d.append(g[1])
-                for k in (0, 2, 3, 4, 5, 6, 7):
-                    if g[k] is not None:
-                        acc[k] = g[k] if acc[k] is None else acc[k].add_(g[k])
+                acc = g
+            acc = list(acc)
             if needs[1] and ctx.means2D_shape is not None:
                 acc[1] = torch.stack(g_m2d) if per_view_means2D else \
                     torch.zeros(ctx.means2D_shape, dtype=torch.float32, device=dev)

@@ -312,9 +312,10 @@ def render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_im
 
 
 def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows,
-                        needs, means2D_shape):
+                        needs, means2D_shape, accumulate_into=None):
     """gs_preprocess_bwd on the current stream.  `needs` = 8 flags in the order of GaussianRasterizer.forward's
-    arguments; returns the 8 gradients (None where not needed)."""
+    arguments; returns the 8 gradients (None where not needed).  accumulate_into = the 8-tuple a previous
+    call returned: this view's gradients are added into those tensors (means2D's, per view, is fresh)."""
     lib = _lib.load()
     dev = means3D.device
     N = means3D.shape[0]
@@ -324,20 +325,24 @@ def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs
     proj = _camera_tensor(settings.projmatrix, 16, "projmatrix", dev)
     campos = _camera_tensor(settings.campos, 3, "campos", dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
     g_means2D = torch.empty(means2D_shape, **f32) if (needs[1] and means2D_shape == (N, 3)) else None
-    g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
-    g_colors = torch.empty((N, 3), **f32) if (colors_precomp is not None and needs[3]) else None
-    g_opac = torch.empty((N, 1), **f32) if needs[4] else None
-    g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
-    g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
-    g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
+    if accumulate_into is not None:
+        g_means3D, _, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov = accumulate_into
+    else:
+        g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
+        g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
+        g_colors = torch.empty((N, 3), **f32) if (colors_precomp is not None and needs[3]) else None
+        g_opac = torch.empty((N, 1), **f32) if needs[4] else None
+        g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
+        g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
+        g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
     with _stage("preprocess_bwd"):
         _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
                                          _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
-                                         _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors), _stream()),
+                                         _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors),
+                                         0 if accumulate_into is None else 1, _stream()),
                    "gs_preprocess_bwd")
     if needs[1] and g_means2D is None and means2D_shape is not None:
         g_means2D = torch.zeros(means2D_shape, **f32)

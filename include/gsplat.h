@@ -138,6 +138,11 @@ int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const
  * trainer reads from viewspace_points.grad (train.py:185-193, scene/gaussian_model.py:701-713):
  * d loss / d screen mean scaled to NDC units (x W/2, y H/2, 0).  Gaussians with radii == 0 get
  * zeros everywhere.
+ * accumulate != 0: the gradients of this view are ADDED to what the g_* buffers hold (rows of
+ * Gaussians with radii == 0 are not touched) -- several views of one batch summed without a pass of
+ * their own, as the multi-view step of parallel.SplatExchange does (no counterpart in the reference,
+ * which renders one view per iteration, train.py:129-135).  g_means2D is a per-view statistic and is
+ * overwritten either way.
  */
 int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                       const float* projmatrix, const float* campos, const float* means3D,
@@ -145,7 +150,7 @@ int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* vi
                       const float* shs, const float* colors_precomp, const int32_t* radii,
                       const float* grad_rows, float* g_means3D, float* g_means2D, float* g_scales,
                       float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
-                      float* g_colors_precomp, void* stream);
+                      float* g_colors_precomp, int accumulate, void* stream);
 
 /*
  * Training loss, fused (the step right after the rasterizer in every iteration).

@@ -36,7 +36,7 @@ def test_loss_matches_reference_goldens(impl, path):
     loss, parts = impl.l1_ssim_loss(img, gt, float(g["lam"]), return_parts=True)   # the reference's sign (train.py:143-145)
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(g["loss"])) <= TOL_LOSS
+    assert abs(float(loss.detach()) - float(g["loss"])) <= TOL_LOSS
     assert abs(float(parts[1]) - float(g["l1"])) <= TOL_LOSS
     assert abs(float(parts[2]) - float(g["ssim"])) <= TOL_LOSS
     err = np.abs(img.grad.cpu().numpy() - g["grad"]).max()

@@ -439,3 +439,51 @@ def test_tile_row_bands_backward_adds_up(dgr):
         banded = grads(world)
         for k in full:
             check_grad(f"bands{world}:d_{k}", banded[k], full[k], rel=2e-5)   # fp32 summation order only
+
+
+@pytest.mark.parametrize("variant", ["sh_deg0_scalar", "sh_deg3_staged", "sh_deg3_K20_vec4", "colors_cov3d"])
+def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
+    """accumulate flag of gs_preprocess_bwd (multi-view batches, parallel.SplatExchange): two views with
+    the flag == the sum of the two views' own gradients; Gaussians culled in the second view keep the first's."""
+    R = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    dev = torch.device("cuda:0")
+    N, H, W = 5000, 120, 168
+    K, deg = {"sh_deg0_scalar": (1, 0), "sh_deg3_staged": (16, 3), "sh_deg3_K20_vec4": (20, 3),
+              "colors_cov3d": (1, 0)}[variant]
+    sc = syn.make_scene(N, K, H, W, seed=11, sh_degree=deg)
+    views = [syn.jitter_view(sc, 0), syn.jitter_view(sc, 5)]
+    m3, sh, op, s, q = (getattr(sc, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
+    colors = cov6 = None
+    if variant == "colors_cov3d":
+        g = torch.Generator().manual_seed(1)
+        colors = torch.rand(N, 3, generator=g).to(dev)
+        Rm = torch.randn(N, 3, 3, generator=g) * 0.05
+        S = Rm @ Rm.transpose(1, 2) + 1e-4 * torch.eye(3)
+        cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous().to(dev)
+        sh = s = q = None
+    rows = torch.randn(N, 16, generator=torch.Generator().manual_seed(2)).to(dev)
+    needs = [True] * 8
+    per_view, radii = [], []
+    for v in views:
+        st = _scene_settings(dgr, v, dev)
+        _, r, *_ = R.preprocess(st, m3, op, s, q, cov6, sh, colors)
+        radii.append(r)
+        per_view.append(R.preprocess_backward(st, m3, s, q, cov6, sh, colors, r, rows, needs, (N, 3)))
+    assert int(((radii[0] > 0) != (radii[1] > 0)).sum()) > 0      # some Gaussians are drawn in one view only
+    acc = None
+    for v, r in zip(views, radii):
+        acc = R.preprocess_backward(_scene_settings(dgr, v, dev), m3, s, q, cov6, sh, colors, r, rows, needs, (N, 3),
+                                    accumulate_into=acc)
+    torch.cuda.synchronize()
+    names = ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "cov3D")
+    for k, name in enumerate(names):
+        a, b = per_view[0][k], per_view[1][k]
+        if a is None:
+            assert acc[k] is None
+            continue
+        want = b if name == "means2D" else a + b
+        if name == "means3D":     # the SH launch adds its share after the geometry launch: one more rounding
+            assert (acc[k] - want).abs().max().item() <= 1e-6 * want.abs().max().item(), name
+        else:
+            assert torch.equal(acc[k], want), name

@@ -116,17 +116,22 @@ def main():
     # N > 1: rank r renders view r of the SAME scene (camera jittered per view), one view per rank and step
     views = [syn.jitter_view(scene, r) if multi else scene for r in range(world)]
     settings = make_settings(views[rank])
-    if exchange:      # this rank owns Gaussians [lo, hi)
-        lo, hi = par.tile_row_band(N, rank, world)
-        params = {k: getattr(scene, k)[lo:hi].to(dev).requires_grad_(True) for k in names}
-        all_settings = [make_settings(v) for v in views]
-        ex = par.SplatExchange(hi - lo, device=dev)
-    else:
-        params = {k: getattr(scene, k).to(dev).requires_grad_(True) for k in names}
     G = scene.G.to(dev)
     rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
-    reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20)) \
-        if (multi and not exchange) else None
+    params, all_settings, ex, reducer = {}, None, None, None
+
+    def setup():
+        nonlocal params, all_settings, ex, reducer
+        params, all_settings, ex, reducer = {}, None, None, None
+        if exchange:      # this rank owns Gaussians [lo, hi)
+            lo, hi = par.tile_row_band(N, rank, world)
+            params = {k: getattr(scene, k)[lo:hi].to(dev).requires_grad_(True) for k in names}
+            all_settings = [make_settings(v) for v in views]
+            ex = par.SplatExchange(hi - lo, device=dev)
+        else:
+            params = {k: getattr(scene, k).to(dev).requires_grad_(True) for k in names}
+            if multi:
+                reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20))
 
     def step():
         if forward_only:
@@ -160,6 +165,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    setup()
+    if exchange:
+        # first use of the all-to-all path on this machine: if RCCL refuses it on any rank, every rank
+        # falls back to the replicated / all-reduce step (reported as such in config.parallelism)
+        ok = 1
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: splat exchange failed ({type(e).__name__}: {e}); using --parallel allreduce",
+                  file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            exchange = False
+            setup()
     for _ in range(args.warmup):
         step()
     fence()

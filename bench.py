@@ -263,13 +263,52 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         }
         if world == 1 and not forward_only:
-            out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev)}
+            out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
+                                "adam_densify_step": bench_adam(impl, params, radii, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_adam(impl, params, radii, dev, iters=10):
+    """SURVEY.md 8f row 2 (outside the headline metric): one fused Adam step over the reference's six parameter
+    groups of the bench scene + the densification statistics, using the gradients the last frame left in .grad.
+    f_dc / f_rest are the column ranges of the SH tensor (their gradients are read in place from the (N,K,3)
+    SH gradient).  Algorithmic bytes: 28 per parameter (p, g, m, v read; p, m, v written) + 32 per Gaussian."""
+    N, K = params["shs"].shape[0], params["shs"].shape[1]
+    g_shs = params["shs"].grad
+    leaves = {"xyz": (params["means3D"], params["means3D"].grad, 0.00016),
+              "f_dc": (params["shs"].detach()[:, :1].contiguous(), g_shs[:, :1], 0.0025),
+              "f_rest": (params["shs"].detach()[:, 1:].contiguous(), g_shs[:, 1:], 0.0025 / 20),
+              "opacity": (params["opacities"], params["opacities"].grad, 0.05),
+              "scaling": (params["scales"], params["scales"].grad, 0.005),
+              "rotation": (params["rotations"], params["rotations"].grad, 0.001)}
+    groups, nparam = [], 0
+    for name, (p, g, lr) in leaves.items():
+        q = torch.nn.Parameter(p.detach().clone())
+        q.grad = g
+        nparam += q.numel()
+        groups.append({"params": [q], "lr": lr, "name": name})
+    opt = impl.FusedAdam(groups, lr=0.0, eps=1e-15)
+    vg = torch.randn(N, 3, device=dev)
+    acc, den, mr = (torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, device=dev))
+    kw = dict(viewspace_grad=vg, radii=radii, xyz_gradient_accum=acc, denom=den, max_radii2D=mr)
+    for _ in range(2):
+        opt.step(**kw)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        opt.step(**kw)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    nbytes = 28 * nparam + 32 * N
+    return {"ms": round(ms, 4), "parameters": nparam, "algorithmic_bytes": nbytes,
+            "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4),
+            "note": "one launch: 6 groups (reference lrs, eps 1e-15) + max_radii2D / xyz_gradient_accum / denom"}
 
 
 def bench_loss(impl, H, W, dev, iters=20):

@@ -7,10 +7,11 @@ The directory name is not a Python identifier; import it through the drop-in pac
 from .rasterizer import (DEFAULT_T_EPS, BinningState, GaussianRasterizationSettings, GaussianRasterizer,
                          preprocess_and_bin, rasterize_gaussians)
 from .loss import l1_ssim_loss
+from .optimizer import FusedAdam
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
-           "preprocess_and_bin", "BinningState", "DEFAULT_T_EPS", "l1_ssim_loss"]
+           "preprocess_and_bin", "BinningState", "DEFAULT_T_EPS", "l1_ssim_loss", "FusedAdam"]
 __version__ = "0.1.0"
 
 # Fail loudly at import: the reference swallows import errors (gaussian_renderer/__init__.py:26-27)

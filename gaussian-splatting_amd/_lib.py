@@ -11,7 +11,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsplat_hip.so")
 
-_vp, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+_vp, _i, _ll, _f, _sz, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
+
+
+class GsAdamGroup(C.Structure):
+    """struct GsAdamGroup of include/gsplat.h"""
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("rows", _ll),
+                ("grad_row_stride", _ll), ("row_len", _i), ("reserved", _i), ("lr", _d)]
+
 
 # name -> (restype, argtypes); mirrors include/gsplat.h one to one
 PROTOTYPES = {
@@ -31,6 +38,7 @@ PROTOTYPES = {
     "gs_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
     "gs_l1_ssim": (_i, [_i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "gs_render_bwd": (_i, [_i, _i] + [_vp] * 10 + [_f, _i, _i, _vp]),
+    "gs_adam_densify_step": (_i, [_i, C.POINTER(GsAdamGroup), _d, _d, _d, _ll, _ll, _i] + [_vp] * 6),
 }
 
 _lib = None

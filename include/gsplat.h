@@ -165,6 +165,38 @@ size_t gs_l1_ssim_workspace_bytes(int C, int H, int W);
 int gs_l1_ssim(int C, int H, int W, const float* img, const float* gt, float w_l1, float w_ssim, float* loss_out,
                float* grad, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Optimizer step + densification statistics, fused (the step right after the backward).
+ * Replaces torch.optim.Adam(l, lr=0.0, eps=1e-15).step() over the reference's six parameter groups
+ * (scene/gaussian_model.py:264-297, train.py:217), the max_radii2D update (train.py:184-187) and
+ * add_densification_stats (scene/gaussian_model.py:701-713) -- one launch instead of ~40.
+ * Arithmetic = torch's Adam (no weight decay / amsgrad / maximize) in fp32, operation by operation.
+ * `groups` is a HOST array; its pointers are device pointers.  A group is a (rows, row_len) fp32 matrix;
+ * param / exp_avg / exp_avg_sq are contiguous, grad may have a row stride (0 = contiguous) so that
+ * column ranges of the rasterizer's (N,K,3) SH gradient can be consumed in place (f_dc: row_len 3,
+ * stride 3K; f_rest: grad + 3, row_len 3(K-1), stride 3K).
+ * step = the 1-based count of this update (torch's state["step"] after incrementing).
+ * Statistics (skipped when radii is NULL or num_views == 0), for every Gaussian i and each view v of the
+ * step with radii[v][i] > 0, in view order:  xyz_gradient_accum[i] += |means2D_grad[v][i][0:2]|,
+ * denom[i] += 1 (both only when means2D_grad is given), max_radii2D[i] = max(., radii[v][i]).
+ * The reference has one view per step (num_views = 1); parallel.SplatExchange returns them per view.
+ */
+typedef struct GsAdamGroup {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long long rows;
+    long long grad_row_stride;   /* in floats; 0 = row_len */
+    int row_len;
+    int reserved;
+    double lr;
+} GsAdamGroup;
+int gs_adam_densify_step(int num_groups, const GsAdamGroup* groups, double beta1, double beta2, double eps,
+                         long long step, long long N, int num_views, const float* means2D_grad,
+                         const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,3 +17,9 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture(scope="session")
+def oracle_adam():
+    from oracle import adam_oracle
+    return adam_oracle

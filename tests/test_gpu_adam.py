@@ -1,0 +1,152 @@
+"""GPU: FusedAdam (gs_adam_densify_step through the C-ABI) against
+  (a) torch.optim.Adam on the same GPU, constructed as the reference constructs it (scene/gaussian_model.py:264-297):
+      bit-identical parameters and moments over several steps, with the xyz learning rate rescheduled each step;
+  (b) the CPU oracle (oracle/adam_oracle.py, GPU rounding form): identical up to the oracle's float64-emulated fma;
+  (c) the densification statistics of train.py:184-187 / scene/gaussian_model.py:710-713 (oracle and a torch restatement).
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from test_adam_oracle import GROUP_LRS, make_grads, make_params  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def impl():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return importlib.import_module("gaussian-splatting_amd")
+
+
+def _groups(tp):
+    return [{"params": [tp[name]], "lr": lr, "name": name} for name, _, lr in GROUP_LRS]
+
+
+@pytest.mark.parametrize("N", [1, 777, 40000])          # 777 * 3 etc.: scalar path; 40000: float4 path
+def test_equals_torch_adam_on_gpu_bit_for_bit(impl, N):
+    dev = torch.device("cuda:0")
+    params = make_params(N, 0)
+    ta = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in params.items()}
+    tb = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in params.items()}
+    ref = torch.optim.Adam(_groups(ta), lr=0.0, eps=1e-15)
+    opt = impl.FusedAdam(_groups(tb), lr=0.0, eps=1e-15)
+    for t in range(1, 7):
+        grads = make_grads(N, 100 + t)
+        lr_xyz = 0.00016 * (0.9 ** t)             # gaussians.update_learning_rate (scene/gaussian_model.py:307-314)
+        for o in (ref, opt):
+            for g in o.param_groups:
+                if g["name"] == "xyz":
+                    g["lr"] = lr_xyz
+        for name in params:
+            ta[name].grad = grads[name].to(dev)
+            tb[name].grad = grads[name].to(dev)
+        ref.step()
+        opt.step()
+        for name in params:
+            sa, sb = ref.state[ta[name]], opt.state[tb[name]]
+            assert torch.equal(sb["exp_avg"], sa["exp_avg"]), (name, t)
+            assert torch.equal(sb["exp_avg_sq"], sa["exp_avg_sq"]), (name, t)
+            assert torch.equal(tb[name], ta[name]), (name, t)
+            assert float(sb["step"]) == float(sa["step"]) == t
+    # state_dict round trip into a fresh torch Adam and back
+    sd = opt.state_dict()
+    ref2 = torch.optim.Adam(_groups(ta), lr=0.0, eps=1e-15)
+    ref2.load_state_dict(sd)
+    assert float(ref2.state[ta["xyz"]]["step"]) == 6
+
+
+def test_strided_sh_gradient_and_oracle(impl, oracle_adam):
+    """f_dc / f_rest gradients consumed in place as column ranges of one (N,K,3) SH gradient (what the
+    rasterizer returns); compared with the oracle in its GPU rounding form."""
+    dev = torch.device("cuda:0")
+    N, K = 5001, 16
+    g = torch.Generator().manual_seed(4)
+    f_dc, f_rest = torch.randn(N, 1, 3, generator=g), torch.randn(N, K - 1, 3, generator=g)
+    p_dc, p_rest = torch.nn.Parameter(f_dc.clone().to(dev)), torch.nn.Parameter(f_rest.clone().to(dev))
+    opt = impl.FusedAdam([{"params": [p_dc], "lr": 0.0025, "name": "f_dc"},
+                          {"params": [p_rest], "lr": 0.0025 / 20, "name": "f_rest"}], lr=0.0, eps=1e-15)
+    o = {"dc": [f_dc.numpy().copy(), np.zeros((N, 1, 3), np.float32), np.zeros((N, 1, 3), np.float32)],
+         "rest": [f_rest.numpy().copy(), np.zeros((N, K - 1, 3), np.float32), np.zeros((N, K - 1, 3), np.float32)]}
+    for t in (1, 2, 3):
+        g_shs = (torch.randn(N, K, 3, generator=g) * 1e-3)
+        gd = g_shs.to(dev)
+        p_dc.grad, p_rest.grad = gd[:, :1, :], gd[:, 1:, :]          # views, row stride 3K
+        assert not p_rest.grad.is_contiguous()
+        opt.step()
+        oracle_adam.adam_step(o["dc"][0], g_shs[:, :1].numpy(), o["dc"][1], o["dc"][2], t, 0.0025)
+        oracle_adam.adam_step(o["rest"][0], g_shs[:, 1:].numpy(), o["rest"][1], o["rest"][2], t, 0.0025 / 20)
+    for key, p in (("dc", p_dc), ("rest", p_rest)):
+        got = p.detach().cpu().numpy()
+        bad = got != o[key][0]
+        assert bad.mean() <= 1e-5, key                                # float64-emulated fma: double rounding is rare
+        assert np.all(np.abs(got - o[key][0]) <= np.spacing(np.abs(o[key][0]))), key
+        assert np.array_equal(opt.state[p]["exp_avg"].cpu().numpy(), o[key][1]) or \
+            (opt.state[p]["exp_avg"].cpu().numpy() != o[key][1]).mean() <= 1e-5
+
+
+@pytest.mark.parametrize("views", [1, 3])
+def test_densification_stats_ride_along(impl, oracle_adam, views):
+    dev = torch.device("cuda:0")
+    N = 3001
+    g = torch.Generator().manual_seed(3)
+    radii = torch.randint(0, 40, (views, N), generator=g, dtype=torch.int32)
+    radii[torch.rand(views, N, generator=g) < 0.4] = 0
+    vg = torch.randn(views, N, 3, generator=g)
+    acc, den = torch.rand(N, 1, generator=g), torch.randint(0, 5, (N, 1), generator=g).float()
+    mr = torch.randint(0, 30, (N,), generator=g).float()
+    oacc, oden, omr = acc.numpy().copy().reshape(N), den.numpy().copy().reshape(N), mr.numpy().copy()
+    oracle_adam.densify_stats(vg.numpy(), radii.numpy(), oacc, oden, omr)
+    p = torch.nn.Parameter(torch.randn(N, 3, generator=g).to(dev))
+    p.grad = torch.randn(N, 3, generator=g).to(dev)
+    ref_p = torch.nn.Parameter(p.detach().clone())
+    ref_p.grad = p.grad.clone()
+    opt = impl.FusedAdam([{"params": [p], "lr": 1e-3, "name": "xyz"}], lr=0.0, eps=1e-15)
+    acc_d, den_d, mr_d = acc.to(dev), den.to(dev), mr.to(dev)
+    rd, vgd = radii.to(dev), vg.to(dev)
+    if views == 1:           # the reference's shapes: (N,) radii, (N,3) viewspace gradient
+        rd, vgd = rd[0], vgd[0]
+    opt.step(viewspace_grad=vgd, radii=rd, xyz_gradient_accum=acc_d, denom=den_d, max_radii2D=mr_d)
+    assert np.array_equal(mr_d.cpu().numpy(), omr)
+    assert np.array_equal(den_d.cpu().numpy().reshape(N), oden)
+    assert np.allclose(acc_d.cpu().numpy().reshape(N), oacc, rtol=1e-6, atol=0)
+    torch.optim.Adam([{"params": [ref_p], "lr": 1e-3}], lr=0.0, eps=1e-15).step()
+    assert torch.equal(p, ref_p)
+    # statistics alone (no parameter has a gradient)
+    p.grad = None
+    before = p.detach().clone()
+    opt.step(radii=rd, max_radii2D=mr_d)
+    assert torch.equal(p, before)
+
+
+def test_reference_state_surgery_and_errors(impl):
+    """The reference prunes / extends optimizer state in place (scene/gaussian_model.py:476-530); FusedAdam
+    keeps torch's state layout, so that code works on it unchanged."""
+    dev = torch.device("cuda:0")
+    p = torch.nn.Parameter(torch.randn(100, 3, device=dev))
+    opt = impl.FusedAdam([{"params": [p], "lr": 1e-3, "name": "xyz"}], lr=0.0, eps=1e-15)
+    p.grad = torch.randn(100, 3, device=dev)
+    opt.step()
+    mask = torch.rand(100, device=dev) > 0.5
+    group = opt.param_groups[0]
+    st = opt.state.get(group["params"][0], None)
+    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+    del opt.state[group["params"][0]]
+    group["params"][0] = torch.nn.Parameter(group["params"][0][mask].requires_grad_(True))
+    opt.state[group["params"][0]] = st
+    q = group["params"][0]
+    q.grad = torch.randn_like(q)
+    opt.step()
+    assert float(opt.state[q]["step"]) == 2
+    with pytest.raises(NotImplementedError):
+        impl.FusedAdam([p], lr=1e-3, weight_decay=0.1)
+    c = torch.nn.Parameter(torch.randn(4, 3))
+    c.grad = torch.randn(4, 3)
+    with pytest.raises(RuntimeError):
+        impl.FusedAdam([c], lr=1e-3).step()

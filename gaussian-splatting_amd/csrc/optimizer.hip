@@ -42,7 +42,7 @@ struct AdGroup {
     unsigned long long magic; // floor(2^64 / row_len) + 1: e / row_len == umul64hi(e, magic) for e < 2^40
     int row_len;
     float neg_step_size;      // -(lr / (1 - beta1^t))
-    int vec4;                 // g contiguous, everything 16-byte aligned, n_elems % 4 == 0
+    int vec4;                 // p, m, v 16-byte aligned and n_elems % 4 == 0: 1 = g too (contiguous), 2 = g strided
     int pad;
 };
 
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(AD_THREADS) void adam_densify_kernel(const AdArgs a
     const long long base = (blk - a.block_begin[gi]) * AD_BLOCK_ELEMS;
     const float neg_step = G.neg_step_size;
     if (G.vec4) {
-        // two float4 per lane, all loads issued before the first use
+        // two float4 per lane, all loads issued before the first use.  vec4 == 2: the gradient is a
+        // strided view, fetched as four dwords (a float4 of parameters may straddle two gradient rows)
         float4 p[2], g[2], m[2], v[2];
         long long e[2];
 #pragma unroll
@@ -114,7 +115,20 @@ __global__ __launch_bounds__(AD_THREADS) void adam_densify_kernel(const AdArgs a
             e[k] = base + ((long long)k * AD_THREADS + threadIdx.x) * 4;
             if (e[k] < G.n_elems) {
                 p[k] = *reinterpret_cast<const float4*>(G.p + e[k]);
-                g[k] = *reinterpret_cast<const float4*>(G.g + e[k]);
+                if (G.vec4 == 1) {
+                    g[k] = *reinterpret_cast<const float4*>(G.g + e[k]);
+                } else {
+                    const unsigned long long row = G.magic ? __umul64hi((unsigned long long)e[k], G.magic) : (unsigned long long)e[k];
+                    int col = (int)(e[k] - (long long)row * G.row_len);
+                    const float* gp = G.g + (long long)row * G.g_row_stride;
+                    float t[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        t[c] = gp[col];
+                        if (++col == G.row_len) { col = 0; gp += G.g_row_stride; }
+                    }
+                    g[k] = make_float4(t[0], t[1], t[2], t[3]);
+                }
                 m[k] = *reinterpret_cast<const float4*>(G.m + e[k]);
                 v[k] = *reinterpret_cast<const float4*>(G.v + e[k]);
             }
@@ -126,9 +140,11 @@ __global__ __launch_bounds__(AD_THREADS) void adam_densify_kernel(const AdArgs a
                 adam_update(p[k].y, g[k].y, m[k].y, v[k].y, a, neg_step);
                 adam_update(p[k].z, g[k].z, m[k].z, v[k].z, a, neg_step);
                 adam_update(p[k].w, g[k].w, m[k].w, v[k].w, a, neg_step);
-                *reinterpret_cast<float4*>(G.p + e[k]) = p[k];
-                *reinterpret_cast<float4*>(G.m + e[k]) = m[k];
-                *reinterpret_cast<float4*>(G.v + e[k]) = v[k];
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                // streamed once per step, far larger than the caches: keep them out of the way of the reads
+                __builtin_nontemporal_store(f4v{p[k].x, p[k].y, p[k].z, p[k].w}, reinterpret_cast<f4v*>(G.p + e[k]));
+                __builtin_nontemporal_store(f4v{m[k].x, m[k].y, m[k].z, m[k].w}, reinterpret_cast<f4v*>(G.m + e[k]));
+                __builtin_nontemporal_store(f4v{v[k].x, v[k].y, v[k].z, v[k].w}, reinterpret_cast<f4v*>(G.v + e[k]));
             }
         }
         return;
@@ -200,8 +216,8 @@ extern "C" int gs_adam_densify_step(int num_groups, const GsAdamGroup* groups, d
         d.row_len = s.row_len;
         d.magic = s.row_len == 1 ? 0ull : ~0ull / (unsigned long long)s.row_len + 1ull;   // 0: row_len 1, row = e
         d.neg_step_size = (float)(-(s.lr / bc1));
-        const uintptr_t al = (uintptr_t)s.param | (uintptr_t)s.grad | (uintptr_t)s.exp_avg | (uintptr_t)s.exp_avg_sq;
-        d.vec4 = (stride == s.row_len && (al & 15) == 0 && n % 4 == 0) ? 1 : 0;
+        const uintptr_t al = (uintptr_t)s.param | (uintptr_t)s.exp_avg | (uintptr_t)s.exp_avg_sq;
+        d.vec4 = ((al & 15) != 0 || n % 4 != 0) ? 0 : (stride == s.row_len && ((uintptr_t)s.grad & 15) == 0) ? 1 : 2;
         a.block_begin[k] = blocks;
         blocks += (n + AD_BLOCK_ELEMS - 1) / AD_BLOCK_ELEMS;
     }

@@ -20,6 +20,13 @@ class GsAdamGroup(C.Structure):
                 ("grad_row_stride", _ll), ("row_len", _i), ("reserved", _i), ("lr", _d)]
 
 
+class GsPlyLayout(C.Structure):
+    """struct GsPlyLayout of include/gsplat.h"""
+    _fields_ = [("num_vertices", _ll), ("data_offset", _ll), ("stride_bytes", _i), ("sh_rest_count", _i),
+                ("off_xyz", _i * 3), ("off_f_dc", _i * 3), ("off_opacity", _i), ("off_scale", _i * 3),
+                ("off_rot", _i * 4), ("off_f_rest", _i * 72)]
+
+
 # name -> (restype, argtypes); mirrors include/gsplat.h one to one
 PROTOTYPES = {
     "gs_version": (_i, []),
@@ -38,6 +45,10 @@ PROTOTYPES = {
     "gs_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
     "gs_l1_ssim": (_i, [_i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "gs_render_bwd": (_i, [_i, _i] + [_vp] * 10 + [_f, _i, _i, _vp]),
+    "gs_ply_parse_header": (_i, [_vp, _sz, _sz, C.POINTER(GsPlyLayout)]),
+    "gs_ply_write_header": (_ll, [_vp, _sz, _ll, _i, C.POINTER(GsPlyLayout)]),
+    "gs_ply_unpack": (_i, [C.POINTER(GsPlyLayout)] + [_vp] * 12),
+    "gs_ply_pack": (_i, [C.POINTER(GsPlyLayout)] + [_vp] * 8),
     "gs_adam_densify_step": (_i, [_i, C.POINTER(GsAdamGroup), _d, _d, _d, _ll, _ll, _i] + [_vp] * 6),
 }
 

@@ -197,6 +197,45 @@ int gs_adam_densify_step(int num_groups, const GsAdamGroup* groups, double beta1
                          const int32_t* radii, float* xyz_gradient_accum, float* denom, float* max_radii2D,
                          void* stream);
 
+/*
+ * Trained-model PLY <-> device layout.  Replaces GaussianModel.load_ply / save_ply
+ * (scene/gaussian_model.py:377-459, :333-375; attribute order :316-331; plyfile underneath).
+ * gs_ply_parse_header (host): reads the ASCII header of a binary_little_endian PLY from the first n_bytes of
+ * the file (the header must end inside them; file_size = size of the whole file, checked against the vertex
+ * count) and fills the layout: vertex count, byte offset of the first record, record stride and the byte offsets of
+ * x y z f_dc_0..2 opacity scale_0..2 rot_0..3 and of the f_rest_* properties in file order (what load_ply
+ * keys on).  Other vertex properties (nx ny nz, ...) are skipped by size; elements after the vertices are
+ * ignored.  gs_ply_unpack (device): `records` = the vertex records copied to the GPU as they are
+ * (file_bytes + data_offset, num_vertices * stride_bytes, 4-byte aligned); writes the parameters exactly
+ * as load_ply builds them -- xyz (N,3), features_dc (N,1,3), features_rest (N,K-1,3) (transposed from the
+ * file's channel-major order), opacity (N,1), scaling (N,3), rotation (N,4) -- and/or the activated
+ * tensors the rasterizer takes (:104-142): shs = cat(dc, rest) (N,K,3), sigmoid(opacity), exp(scaling),
+ * normalize(rotation).  Any output may be NULL.  gs_ply_write_header / gs_ply_pack: the inverse, the
+ * file save_ply writes (normals zero).
+ */
+#define GS_PLY_MAX_REST 72
+typedef struct GsPlyLayout {
+    long long num_vertices;
+    long long data_offset;
+    int stride_bytes;
+    int sh_rest_count;
+    int off_xyz[3];
+    int off_f_dc[3];
+    int off_opacity;
+    int off_scale[3];
+    int off_rot[4];
+    int off_f_rest[GS_PLY_MAX_REST];
+} GsPlyLayout;
+int gs_ply_parse_header(const void* file_bytes, size_t n_bytes, size_t file_size, GsPlyLayout* layout);
+/* returns the header length; writes it when buf is large enough; fills *layout (may be NULL) */
+long long gs_ply_write_header(char* buf, size_t cap, long long num_vertices, int sh_rest_count, GsPlyLayout* layout);
+int gs_ply_unpack(const GsPlyLayout* layout, const void* records, float* xyz, float* features_dc,
+                  float* features_rest, float* opacity, float* scaling, float* rotation, float* shs,
+                  float* opacities_act, float* scales_act, float* rotations_act, void* stream);
+int gs_ply_pack(const GsPlyLayout* layout, void* records, const float* xyz, const float* features_dc,
+                const float* features_rest, const float* opacity, const float* scaling, const float* rotation,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

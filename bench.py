@@ -264,13 +264,44 @@ def main():
         }
         if world == 1 and not forward_only:
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
-                                "adam_densify_step": bench_adam(impl, params, radii, dev)}
+                                "adam_densify_step": bench_adam(impl, params, radii, dev),
+                                "ply_unpack": bench_ply(N, K, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_ply(N, K, dev, iters=10):
+    """SURVEY.md 8f row 3 (outside the headline metric): unpack N vertex records of a trained-model PLY (already in
+    HBM) into the six parameter tensors + the four activated rasterizer inputs.  Algorithmic bytes: the records
+    read once, every output written once."""
+    import ctypes as C
+    lib_mod = importlib.import_module("gaussian-splatting_amd._lib")
+    lib = lib_mod.load()
+    layout = lib_mod.GsPlyLayout()
+    R = 3 * (K - 1)
+    lib.gs_ply_write_header(None, 0, N, R, C.byref(layout))
+    rec = torch.randn(N * layout.stride_bytes // 4, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    outs = [torch.empty((N, w), **f32) for w in (3, 3, R, 1, 3, 4, R + 3, 1, 3, 4)]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: lib_mod.check(lib.gs_ply_unpack(C.byref(layout), C.c_void_p(rec.data_ptr()),  # noqa: E731
+                                                   *[C.c_void_p(o.data_ptr()) for o in outs], st), "gs_ply_unpack")
+    for _ in range(2):
+        call()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        call()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    nbytes = rec.numel() * 4 + sum(o.numel() for o in outs) * 4
+    return {"ms": round(ms, 4), "algorithmic_bytes": nbytes, "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4)}
 
 
 def bench_adam(impl, params, radii, dev, iters=10):

@@ -9,10 +9,11 @@ from .rasterizer import (DEFAULT_T_EPS, BinningState, GaussianRasterizationSetti
 from .loss import l1_ssim_loss
 from .optimizer import FusedAdam
 from .ply_io import load_ply, save_ply
+from .knn import distCUDA2
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
-           "preprocess_and_bin", "BinningState", "DEFAULT_T_EPS", "l1_ssim_loss", "FusedAdam", "load_ply", "save_ply"]
+           "preprocess_and_bin", "BinningState", "DEFAULT_T_EPS", "l1_ssim_loss", "FusedAdam", "load_ply", "save_ply", "distCUDA2"]
 __version__ = "0.1.0"
 
 # Fail loudly at import: the reference swallows import errors (gaussian_renderer/__init__.py:26-27)

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "gs_ply_write_header": (_ll, [_vp, _sz, _ll, _i, C.POINTER(GsPlyLayout)]),
     "gs_ply_unpack": (_i, [C.POINTER(GsPlyLayout)] + [_vp] * 12),
     "gs_ply_pack": (_i, [C.POINTER(GsPlyLayout)] + [_vp] * 8),
+    "gs_nearest_dist2_workspace_bytes": (_sz, [_ll]),
+    "gs_nearest_dist2": (_i, [_ll, _vp, _vp, _vp, _sz, _vp, _vp]),
     "gs_adam_densify_step": (_i, [_i, C.POINTER(GsAdamGroup), _d, _d, _d, _ll, _ll, _i] + [_vp] * 6),
 }
 

@@ -236,6 +236,19 @@ int gs_ply_pack(const GsPlyLayout* layout, void* records, const float* xyz, cons
                 const float* features_rest, const float* opacity, const float* scaling, const float* rotation,
                 void* stream);
 
+/*
+ * Squared distance of every point to its nearest other point.  Replaces distCUDA2
+ * (scene/gaussian_model.py:729-746: N x N torch.cdist, diagonal = inf, row minimum, squared; out of memory
+ * at 100 k points), which initialises the scales from the SfM cloud (:212-217).  points (N,3) fp32 device,
+ * dist2 (N,) fp32 device; a single point gets +inf, as in the reference.  Uniform grid + the library's radix
+ * sort, exact; O(N) memory (workspace: 256-byte aligned device memory).  Synchronises the stream once (reads
+ * the bounding box back to size the grid).  stats (host, 4 ints, may be NULL; a second sync when given):
+ * grid dims x y z and the number of isolated points settled by the brute-force pass.
+ */
+size_t gs_nearest_dist2_workspace_bytes(long long N);
+int gs_nearest_dist2(long long N, const float* points, float* dist2, void* workspace, size_t workspace_bytes,
+                     int* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,13 +265,30 @@ def main():
         if world == 1 and not forward_only:
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
                                 "adam_densify_step": bench_adam(impl, params, radii, dev),
-                                "ply_unpack": bench_ply(N, K, dev)}
+                                "ply_unpack": bench_ply(N, K, dev),
+                                "nearest_dist2": bench_knn(params["means3D"].detach(), dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_knn(points, dev, iters=5):
+    """SURVEY.md 8f row 4 (outside the headline metric): distCUDA2 on the bench scene's means (the reference's
+    N x N torch.cdist cannot run at this size: 3 M points = 36 TB)."""
+    knn = importlib.import_module("gaussian-splatting_amd.knn")
+    d, st = knn.distCUDA2(points, return_stats=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        knn.distCUDA2(points)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"ms": round(ms, 3), "points": points.shape[0], "Mpoints_per_s": round(points.shape[0] / ms / 1e3, 1),
+            "grid": list(st["grid"]), "isolated_points": st["isolated"],
+            "note": "wall time incl. the bounding-box read-back; exact 1-NN, O(N) memory"}
 
 
 def bench_ply(N, K, dev, iters=10):

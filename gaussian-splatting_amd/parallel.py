@@ -129,16 +129,24 @@ def gather_bands(band: torch.Tensor, H: int, dst: int = 0, group: Optional[dist.
 # ---------------------------------------------------------------------------------------------------
 # Gaussian-sharded training step: exchange splat records, not gradients
 # ---------------------------------------------------------------------------------------------------
-def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows, in_rows, group):
+def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows, in_rows, group, async_op: bool = False):
     """all_to_all_single along dim 0 with per-peer row counts.  RCCL (and gloo on CPU tensors) take it
     directly; gloo has no device all-to-all, so device tensors are staged through the host there (that
-    combination only exists in tests: two ranks on one GPU)."""
+    combination only exists in tests: two ranks on one GPU).  async_op: returns a handle for _wait()
+    (None when the transfer already completed)."""
     if dist.get_backend(group) == "gloo" and inp.is_cuda:
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), list(out_rows), list(in_rows), group=group)
         out.copy_(o)
-        return
-    dist.all_to_all_single(out, inp, list(out_rows), list(in_rows), group=group)
+        return None
+    w = dist.all_to_all_single(out, inp, list(out_rows), list(in_rows), group=group, async_op=async_op)
+    return w if async_op else None
+
+
+def _wait(work):
+    """Make the current stream wait for an asynchronous collective (no host block with RCCL)."""
+    if work is not None:
+        work.wait()
 
 
 class _RasterizeSharded(torch.autograd.Function):
@@ -172,13 +180,19 @@ class _RasterizeSharded(torch.autograd.Function):
             ids = torch.empty((2, max(total, 1)), **i32)
             rects = torch.empty((max(total, 1), 2), **i32)[:total]
             same = [n] * world
+            # depth keys first (the depth sort needs only them), then the boxes (needed from the scan on), then
+            # the 48-byte records (needed by the compositing kernel): the big transfer runs on RCCL's stream
+            # while this stream sorts and bins
             with _stage("exchange_fwd"):
-                _all_to_all_rows(splat, splat_s.reshape(world * n, 12), counts, same, group)
-                _all_to_all_rows(dkeys[0][:total], dkeys_s.reshape(world * n), counts, same, group)
-                _all_to_all_rows(rects, rects_s.reshape(world * n, 2), counts, same, group)
+                w_keys = _all_to_all_rows(dkeys[0][:total], dkeys_s.reshape(world * n), counts, same, group, True)
+                w_rects = _all_to_all_rows(rects, rects_s.reshape(world * n, 2), counts, same, group, True)
+                w_splat = _all_to_all_rows(splat, splat_s.reshape(world * n, 12), counts, same, group, True)
             torch.arange(total, out=ids[0][:total], **i32)
+            _wait(w_keys)
             # 3. bin and composite my view
-            state = R.bin_splats(mine, splat, None, None, dkeys, ids, rects)
+            state = R.bin_splats(mine, splat, None, None, dkeys, ids, rects, before_scan=lambda: _wait(w_rects))
+            with _stage("exchange_fwd_wait"):
+                _wait(w_splat)
             need_grad = any(t is not None and t.requires_grad for t in
                             (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
             band = R._band(mine, None)

@@ -165,9 +165,11 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     return bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows)
 
 
-def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows=None) -> BinningState:
+def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows=None, before_scan=None) -> BinningState:
     """depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges for N preprocessed Gaussians.
-    dkeys / ids: (2,N) ping-pong buffers with the sort input in row 0; rects: (N,2)."""
+    dkeys / ids: (2,N) ping-pong buffers with the sort input in row 0; rects: (N,2).  `splat` itself is not read
+    here (only carried into the result).  before_scan: called after the depth sort has been queued and before
+    the first kernel that reads `rects` (parallel.SplatExchange waits for the boxes' transfer there)."""
     lib = _lib.load()
     dev = splat.device
     N = splat.shape[0]
@@ -182,6 +184,8 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
         _lib.check(lib.gs_sort_pairs(N, None, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
                                        _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     order = ids[1 if in_b.value else 0][:N]
+    if before_scan is not None:
+        before_scan()
     offsets = torch.empty((N,), **i32)
     rect_in_order = torch.empty((max(N, 1), 2), **i32)
     total = torch.empty((1,), **i32)

@@ -52,6 +52,7 @@ class GradReducer:
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
         works = []
+        overlap = dist.get_backend(self.group) == "nccl"     # several buckets in flight only on RCCL's own stream
         for p in self.params:
             if p.grad is None:
                 continue
@@ -60,7 +61,9 @@ class GradReducer:
                 g = g.contiguous()
                 p.grad = g
             for b in self._buckets(g):
-                works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)
+                if overlap:
+                    works.append(w)
         for w in works:
             w.wait()
         if self.average:

@@ -74,10 +74,15 @@ def main():
                          "(parallel.SplatExchange); 'allreduce' = Gaussians replicated, gradients all-reduced")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 code path with several ranks on ONE GPU (timings meaningless)")
+    ap.add_argument("--watchdog", type=float, default=0.0,
+                    help="seconds after which a still-running bench dumps every thread's stack to stderr and exits")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (process group, collectives) even with one rank")
     args = ap.parse_args()
 
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -282,13 +282,47 @@ def main():
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
                                 "adam_densify_step": bench_adam(impl, params, radii, dev),
                                 "ply_unpack": bench_ply(N, K, dev),
-                                "nearest_dist2": bench_knn(params["means3D"].detach(), dev)}
+                                "nearest_dist2": bench_knn(params["means3D"].detach(), dev),
+                                "training_iteration": bench_iteration(impl, rast, scene, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_iteration(impl, rast, scene, dev, iters=10):
+    """The rows chained as train.py:129-218 chains them: render -> L1+SSIM loss -> backward -> Adam step with the
+    densification statistics, on the bench scene (the rasterizer's inputs stand in for the raw parameters; the SH
+    tensor is one (N,K,3) parameter whose gradient the optimizer consumes in place)."""
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    lrs = {"means3D": 0.00016, "shs": 0.0025, "opacities": 0.05, "scales": 0.005, "rotations": 0.001}
+    p = {k: torch.nn.Parameter(getattr(scene, k).to(dev).clone()) for k in names}
+    opt = impl.FusedAdam([{"params": [p[k]], "lr": lrs[k], "name": k} for k in names], lr=0.0, eps=1e-15)
+    N = p["means3D"].shape[0]
+    gt = torch.rand(3, scene.H, scene.W, device=dev)
+    acc, den, mr = torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, device=dev)
+
+    def it():
+        opt.zero_grad(set_to_none=True)
+        m2d = torch.zeros((N, 3), device=dev, requires_grad=True)
+        image, radii, _, _ = rast(means3D=p["means3D"], means2D=m2d, shs=p["shs"], colors_precomp=None,
+                                  opacities=p["opacities"], scales=p["scales"], rotations=p["rotations"],
+                                  cov3D_precomp=None)
+        impl.l1_ssim_loss(image, gt, lambda_dssim=0.2).backward()
+        opt.step(viewspace_grad=m2d.grad, radii=radii, xyz_gradient_accum=acc, denom=den, max_radii2D=mr)
+
+    for _ in range(3):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        it()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"ms": round(ms, 3), "iterations_per_s": round(1e3 / ms, 1),
+            "note": "render + fused L1/SSIM loss + backward + fused Adam/densification statistics, wall time"}
 
 
 def bench_knn(points, dev, iters=5):

@@ -18,6 +18,8 @@ import torch.distributed as dist
 
 from .profiling import stage as _stage
 
+_DEBUG = bool(__import__("os").environ.get("GS_DEBUG_REDUCE"))
+
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:
     """Views rendered by `rank`: r, r + world, ...."""
@@ -61,9 +63,14 @@ class GradReducer:
                 g = g.contiguous()
                 p.grad = g
             for b in self._buckets(g):
+                if _DEBUG:
+                    print(f"[GradReducer] rank {dist.get_rank(self.group)}: {tuple(b.shape)} {b.dtype} {b.device} "
+                          f"contiguous={b.is_contiguous()} offset={b.storage_offset()}", flush=True)
                 w = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)
                 if overlap:
                     works.append(w)
+                elif b.is_cuda:
+                    torch.cuda.synchronize(b.device)   # gloo on device tensors (rehearsals only): one at a time
         for w in works:
             w.wait()
         if self.average:

@@ -1,36 +1,55 @@
-"""CPU-only, build container only: the UNMODIFIED reference discovers this back-end.
+"""CPU-only, build container only: the reference's import slot and adapter call, checked STATICALLY.
 
+The reference's source is read as text (nothing from it is imported or executed: DESIGN.md section 2, "Denial
+recorded"); an earlier version of this test ran the unmodified reference in a subprocess and saw
+CUDA_RASTERIZER_AVAILABLE become True with this back-end -- that result stands, this is what can still be checked:
+  * the import statement the reference uses (gaussian_renderer/__init__.py:19-23) names a module and two classes that
+    this repository provides;
+  * every keyword the adapter passes to the settings constructor (:563-577) and to the rasterizer call (:623-632, and
+    the alternative spelling at :637) is a parameter of ours, so neither TypeError retry is taken.
 Skipped wherever /root/reference is absent (the GPU box); nothing from it is copied."""
+import inspect
 import os
-import subprocess
-import sys
+import re
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = "/root/reference"
+SRC = "/root/reference/gaussian_renderer/__init__.py"
 
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gaussian_renderer")),
-                                reason="reference checkout not present")
-
-PROBE = r"""
-import sys
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
-import gaussian_renderer as gr
-import diff_gaussian_rasterization as ours
-assert gr.CUDA_RASTERIZER_AVAILABLE is True, "reference did not pick the back-end up"
-assert gr.CUDAGaussianRasterizer is ours.GaussianRasterizer
-assert gr.CUDAGaussianRasterizationSettings is ours.GaussianRasterizationSettings
-# the adapter's settings call (gaussian_renderer/__init__.py:563-583) constructs without the TypeError retry
-import torch
-s = gr.CUDAGaussianRasterizationSettings(image_height=8, image_width=8, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3),
-    scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0, campos=torch.zeros(3),
-    prefiltered=False, debug=False, antialiasing=False)
-r = gr.CUDAGaussianRasterizer(raster_settings=s)
-print("OK")
-"""
+pytestmark = pytest.mark.skipif(not os.path.isfile(SRC), reason="reference checkout not present")
 
 
-def test_reference_imports_our_backend():
-    out = subprocess.run([sys.executable, "-c", PROBE, ROOT, REF], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+def _dict_keys(text, name):
+    m = re.search(name + r"\s*=\s*\{(.*?)\n\s*\}", text, re.S)
+    assert m, f"{name} not found in the reference's adapter"
+    return re.findall(r'"(\w+)"\s*:', m.group(1))
+
+
+def test_reference_import_slot_and_adapter_keywords_match_our_backend():
+    text = open(SRC).read()
+    m = re.search(r"from\s+(\w+)\s+import\s*\(\s*(\w+)\s+as\s+\w+,\s*(\w+)\s+as\s+\w+,?\s*\)", text)
+    assert m, "the reference's optional-import statement was not found"
+    module, cls_a, cls_b = m.groups()
+    assert os.path.isfile(os.path.join(ROOT, module, "__init__.py")), f"no top-level package named {module} here"
+    import importlib
+    ours = importlib.import_module(module)
+    settings_cls, raster_cls = getattr(ours, cls_a), getattr(ours, cls_b)
+    assert {cls_a, cls_b} == {"GaussianRasterizationSettings", "GaussianRasterizer"}
+
+    want = _dict_keys(text, "settings_kwargs")
+    assert "antialiasing" in want and len(want) == 13
+    have = inspect.signature(settings_cls.__init__).parameters
+    assert all(k in have for k in want), [k for k in want if k not in have]
+    assert "raster_settings" in inspect.signature(raster_cls.__init__).parameters
+
+    call = _dict_keys(text, "raster_kwargs")
+    fwd = inspect.signature(raster_cls.forward).parameters
+    assert all(k in fwd for k in call), [k for k in call if k not in fwd]
+    assert "cov3Ds_precomp" in fwd          # the reference's retry spelling is accepted too
+
+    import torch
+    s = settings_cls(image_height=8, image_width=8, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3), scale_modifier=1.0,
+                     viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0, campos=torch.zeros(3),
+                     prefiltered=False, debug=False, antialiasing=False)
+    raster_cls(raster_settings=s)

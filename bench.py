@@ -203,7 +203,8 @@ def main():
     prof.enable()
     for _ in range(3):
         step()
-    stage_ms = prof.disable_and_collect()
+    stage_ms, stage_calls = prof.disable_and_collect(with_counts=True)
+    calls_per_step = {k: v / 3.0 for k, v in stage_calls.items()}
     # the roofline line is about the path's dominant KERNEL; exchange stages (stream waits on RCCL) are reported
     # in stage_ms but are not candidates
     kernel_stages = ("render_bwd", "render_fwd", "preprocess_fwd", "preprocess_bwd", "sort_pairs", "sort_depth",
@@ -278,6 +279,14 @@ def main():
                           "frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 4)},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         }
+        if multi:   # several launches of a stage per step (one per view): mean per launch above, launches here
+            out["stage_launches_per_step"] = {k: round(v, 2) for k, v in calls_per_step.items() if v != 1.0}
+            if exchange:
+                n_loc = params["means3D"].shape[0]
+                out["exchange_bytes_per_rank_and_step"] = {
+                    "forward_out": (world - 1) * n_loc * 60, "backward_in": (world - 1) * n_loc * 64,
+                    "note": "60 B (record 48 + depth key 4 + box 8) per local Gaussian and remote view out, "
+                            "64 B gradient row per local Gaussian and remote view back"}
         if world == 1 and not forward_only:
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
                                 "adam_densify_step": bench_adam(impl, params, radii, dev),

@@ -10,8 +10,9 @@
 //   dL/dx = w_ssim / M * (blur(dS/dmu1) + 2 x blur(dS/dE11) + y blur(dS/dE12)) + w_l1 / M * sign(x - y)
 // (the window is symmetric, so the adjoint of the zero-padded correlation is the same blur).
 //
-// The 2-D window is separable: every 32x16 tile stages its 42x26 halo in LDS, blurs rows, then
-// columns, each lane producing 4 (rows) / 2 (columns) adjacent outputs from a sliding window held in registers.  HBM-bound and tiny next to the rasterizer: 8 B read + 12 B written per pixel-channel
+// The 2-D window is separable: every 32x32 tile stages its 42x42 halo in LDS, blurs rows, then
+// columns, each lane producing 4 adjacent outputs per pass from a sliding window held in registers.
+// Tiny next to the rasterizer: 8 B read + 12 B written per pixel-channel
 // forward, 20 B read + 4 B written backward.  Per-workgroup partial sums and a one-workgroup
 // final reduction keep the loss value bit-reproducible (no float atomics).
 #include "gsplat_common.h"
@@ -27,6 +28,7 @@ constexpr int LP = LH + 1;          // padded LDS row
 constexpr int LQ = 4;               // outputs per lane in the row pass (sliding window in registers)
 constexpr int LQY = 4;              // outputs per lane in the column pass
 constexpr int LTHREADS = 256;
+constexpr int LNLOAD = (LHY * LH + LTHREADS - 1) / LTHREADS;   // halo elements per lane (7)
 
 // The reference's gaussian(11, 1.5), float32, bit for bit (tests/golden/loss/_window_1d.npz): the
 // values sum to 1 - 3.1e-8, and sigma = E[x^2] - mu^2 cancels so badly that a window summing to
@@ -64,12 +66,27 @@ __global__ __launch_bounds__(LTHREADS) void l1_ssim_fwd_kernel(int H, int W, con
     const size_t plane = (size_t)H * W;
     const float* px = img + ch * plane;
     const float* py = gt + ch * plane;
-    for (int e = threadIdx.x; e < LHY * LH; e += LTHREADS) {
-        const int r = e / LH, c = e % LH;
-        const int yy = y0 + r - LR, xx = x0 + c - LR;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        sx[r][c] = in ? px[(size_t)yy * W + xx] : 0.0f;     // conv2d zero padding
-        sy[r][c] = in ? py[(size_t)yy * W + xx] : 0.0f;
+    {   // halo tile -> LDS; all of a lane's loads are issued before the first LDS write (one HBM round trip, not 7)
+        float vx[LNLOAD], vy[LNLOAD];
+#pragma unroll
+        for (int i = 0; i < LNLOAD; ++i) {
+            const int e = threadIdx.x + i * LTHREADS, r = e / LH, c = e % LH;
+            const int yy = y0 + r - LR, xx = x0 + c - LR;
+            const bool in = e < LHY * LH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t o = (size_t)(in ? yy : 0) * W + (in ? xx : 0);
+            vx[i] = px[o];
+            vy[i] = py[o];
+            vx[i] = in ? vx[i] : 0.0f;     // conv2d zero padding
+            vy[i] = in ? vy[i] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < LNLOAD; ++i) {
+            const int e = threadIdx.x + i * LTHREADS, r = e / LH, c = e % LH;
+            if (e < LHY * LH) {
+                sx[r][c] = vx[i];
+                sy[r][c] = vy[i];
+            }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < LHY * (LT / LQ); e += LTHREADS) {   // blur rows
@@ -172,13 +189,28 @@ __global__ __launch_bounds__(LTHREADS) void l1_ssim_bwd_kernel(int H, int W, con
     __shared__ float hb[3][LHY][LT + 1];
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LTY, ch = blockIdx.z;
     const size_t plane = (size_t)H * W, CHW = gridDim.z * plane;
-    for (int e = threadIdx.x; e < LHY * LH; e += LTHREADS) {
-        const int r = e / LH, c = e % LH;
-        const int yy = y0 + r - LR, xx = x0 + c - LR;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const size_t o = ch * plane + (size_t)(in ? yy : 0) * W + (in ? xx : 0);
+    {   // as in the forward: every load in flight before the first LDS write
+        float v[LNLOAD][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) sd[a][r][c] = in ? dmaps[a * CHW + o] : 0.0f;
+        for (int i = 0; i < LNLOAD; ++i) {
+            const int e = threadIdx.x + i * LTHREADS, r = e / LH, c = e % LH;
+            const int yy = y0 + r - LR, xx = x0 + c - LR;
+            const bool in = e < LHY * LH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t o = ch * plane + (size_t)(in ? yy : 0) * W + (in ? xx : 0);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                v[i][a] = dmaps[a * CHW + o];
+                v[i][a] = in ? v[i][a] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LNLOAD; ++i) {
+            const int e = threadIdx.x + i * LTHREADS, r = e / LH, c = e % LH;
+            if (e < LHY * LH) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) sd[a][r][c] = v[i][a];
+            }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < LHY * (LT / LQ); e += LTHREADS) {

@@ -29,13 +29,11 @@ struct PlyDev {
     int off_rest[GS_PLY_MAX_REST]; // dword offsets of f_rest_j in file order
 };
 
-__device__ __forceinline__ int rest_src(const int* s_off_rest, int coeffs, int k, int c) {
-    // parameter layout (k, c) <- file layout c * coeffs + k   (coeffs = K - 1)
-    return s_off_rest[c * coeffs + k];
-}
-
-template <bool PACK>
-__global__ __launch_bounds__(PLY_THREADS) void ply_kernel(long long N, PlyDev L, uint32_t* __restrict__ records,
+// RT: the f_rest count when known at compile time (0 / 9 / 24 / 45 = degree 0..3: the divisions by the row widths
+// become multiply-shifts), -1 = read it from the layout.  CONTIG: f_rest_j sits at off_rest[0] + j (every file the
+// reference writes): no offset table lookups.
+template <bool PACK, int RT, bool CONTIG>
+__global__ __launch_bounds__(PLY_THREADS) void ply_kernel(long long N, PlyDev L, bool aligned16, uint32_t* __restrict__ records,
                                                            float* __restrict__ xyz, float* __restrict__ f_dc,
                                                            float* __restrict__ f_rest, float* __restrict__ opacity,
                                                            float* __restrict__ scaling, float* __restrict__ rotation,
@@ -53,19 +51,43 @@ __global__ __launch_bounds__(PLY_THREADS) void ply_kernel(long long N, PlyDev L,
     const int S = L.stride_dw;
     uint32_t* rec = lds + wave * 64 * S;
     uint32_t* g_rec = records + i0 * S;
-    const int R = L.rest, coeffs = R / 3;
+    const int R = RT >= 0 ? RT : L.rest, coeffs = R / 3;
+    const int Rd = (RT >= 0 ? RT : L.rest) > 0 ? (RT >= 0 ? RT : L.rest) : 1;   // divisor (no f_rest: loops are empty)
+    const int rest0 = L.off_rest[0];
     auto F = [&](int gi, int off_dw) -> uint32_t& { return rec[gi * S + off_dw]; };
+    auto rest_at = [&](int k, int c) -> int {     // parameter (k, c) <- file column c * coeffs + k
+        return CONTIG ? rest0 + c * coeffs + k : s_off_rest[c * coeffs + k];
+    };
     if (!PACK) {
-        for (int m = lane; m < cnt * S; m += 64) rec[m] = g_rec[m];
+        {   // 64 records = 256 S bytes, a multiple of 16: 16-byte loads, eight in flight per lane
+            const int n4 = (cnt * S) / 4;
+            const uint4* g4 = reinterpret_cast<const uint4*>(g_rec);
+            uint4* r4 = reinterpret_cast<uint4*>(rec);
+            int m = lane;
+            if (aligned16) {
+                for (; m + 7 * 64 < n4; m += 8 * 64) {
+                    uint4 t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = g4[m + 64 * k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) r4[m + 64 * k] = t[k];
+                }
+                for (; m < n4; m += 64) r4[m] = g4[m];
+                for (int t = 4 * n4 + lane; t < cnt * S; t += 64) rec[t] = g_rec[t];
+            } else {
+                for (; m < cnt * S; m += 64) rec[m] = g_rec[m];
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // every output: one contiguous run of this wave's Gaussians, lane m -> (Gaussian m / width, column m % width)
         if (xyz) for (int m = lane; m < cnt * 3; m += 64) xyz[i0 * 3 + m] = __uint_as_float(F(m / 3, L.off[m % 3]));
         if (f_dc) for (int m = lane; m < cnt * 3; m += 64) f_dc[i0 * 3 + m] = __uint_as_float(F(m / 3, L.off[3 + m % 3]));
         if (f_rest)
+#pragma unroll 4
             for (int m = lane; m < cnt * R; m += 64) {
-                const int gi = m / R, j = m - gi * R;
-                f_rest[i0 * R + m] = __uint_as_float(F(gi, rest_src(s_off_rest, coeffs, j / 3, j % 3)));
+                const int gi = m / Rd, j = m - gi * Rd;
+                f_rest[i0 * R + m] = __uint_as_float(F(gi, rest_at(j / 3, j % 3)));
             }
         if (opacity && lane < cnt) opacity[i0 + lane] = __uint_as_float(F(lane, L.off[6]));
         if (scaling) for (int m = lane; m < cnt * 3; m += 64) scaling[i0 * 3 + m] = __uint_as_float(F(m / 3, L.off[7 + m % 3]));
@@ -73,9 +95,10 @@ __global__ __launch_bounds__(PLY_THREADS) void ply_kernel(long long N, PlyDev L,
         // ---- what the rasterizer takes (reference :104-142): shs = cat(f_dc, f_rest), sigmoid, exp, normalize
         if (shs) {
             const int RL = R + 3;
+#pragma unroll 4
             for (int m = lane; m < cnt * RL; m += 64) {
                 const int gi = m / RL, j = m - gi * RL, k = j / 3, c = j % 3;
-                shs[i0 * RL + m] = __uint_as_float(k == 0 ? F(gi, L.off[3 + c]) : F(gi, rest_src(s_off_rest, coeffs, k - 1, c)));
+                shs[i0 * RL + m] = __uint_as_float(k == 0 ? F(gi, L.off[3 + c]) : F(gi, rest_at(k - 1, c)));
             }
         }
         if (opacity_act && lane < cnt) opacity_act[i0 + lane] = 1.0f / (1.0f + expf(-__uint_as_float(F(lane, L.off[6]))));
@@ -96,14 +119,15 @@ __global__ __launch_bounds__(PLY_THREADS) void ply_kernel(long long N, PlyDev L,
         for (int m = lane; m < cnt * 3; m += 64) F(m / 3, L.off[m % 3]) = __float_as_uint(xyz[i0 * 3 + m]);
         for (int m = lane; m < cnt * 3; m += 64) F(m / 3, L.off[3 + m % 3]) = __float_as_uint(f_dc[i0 * 3 + m]);
         for (int m = lane; m < cnt * R; m += 64) {
-            const int gi = m / R, j = m - gi * R;
-            F(gi, rest_src(s_off_rest, coeffs, j / 3, j % 3)) = __float_as_uint(f_rest[i0 * R + m]);
+            const int gi = m / Rd, j = m - gi * Rd;
+            F(gi, rest_at(j / 3, j % 3)) = __float_as_uint(f_rest[i0 * R + m]);
         }
         if (lane < cnt) F(lane, L.off[6]) = __float_as_uint(opacity[i0 + lane]);
         for (int m = lane; m < cnt * 3; m += 64) F(m / 3, L.off[7 + m % 3]) = __float_as_uint(scaling[i0 * 3 + m]);
         for (int m = lane; m < cnt * 4; m += 64) F(m / 4, L.off[10 + m % 4]) = __float_as_uint(rotation[i0 * 4 + m]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
         for (int m = lane; m < cnt * S; m += 64) g_rec[m] = rec[m];
     }
 }
@@ -282,12 +306,25 @@ static int ply_launch(bool pack, const GsPlyLayout* layout, void* records, float
     const long long waves = (N + 63) / 64;
     const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
     hipStream_t stream = (hipStream_t)stream_;
-    if (pack)
-        hipLaunchKernelGGL((ply_kernel<true>), grid, block, lds_bytes, stream, N, D, (uint32_t*)records, xyz, f_dc, f_rest,
-                           opacity, scaling, rotation, shs, opacity_act, scales_act, rotations_act);
-    else
-        hipLaunchKernelGGL((ply_kernel<false>), grid, block, lds_bytes, stream, N, D, (uint32_t*)records, xyz, f_dc, f_rest,
-                           opacity, scaling, rotation, shs, opacity_act, scales_act, rotations_act);
+    const bool aligned16 = ((uintptr_t)records & 15) == 0;
+    bool contig = true;
+    for (int j = 1; j < D.rest; ++j) contig = contig && D.off_rest[j] == D.off_rest[0] + j;
+#define GS_PLY_LAUNCH(PACK_, RT_, CONTIG_)                                                                          \
+    hipLaunchKernelGGL((ply_kernel<PACK_, RT_, CONTIG_>), grid, block, lds_bytes, stream, N, D, aligned16,           \
+                       (uint32_t*)records, xyz, f_dc, f_rest, opacity, scaling, rotation, shs, opacity_act,          \
+                       scales_act, rotations_act)
+#define GS_PLY_DISPATCH(PACK_)                                                   \
+    do {                                                                         \
+        if (contig && D.rest == 45) GS_PLY_LAUNCH(PACK_, 45, true);              \
+        else if (contig && D.rest == 24) GS_PLY_LAUNCH(PACK_, 24, true);         \
+        else if (contig && D.rest == 9) GS_PLY_LAUNCH(PACK_, 9, true);           \
+        else if (D.rest == 0) GS_PLY_LAUNCH(PACK_, 0, true);                     \
+        else GS_PLY_LAUNCH(PACK_, -1, false);                                    \
+    } while (0)
+    if (pack) GS_PLY_DISPATCH(true);
+    else GS_PLY_DISPATCH(false);
+#undef GS_PLY_DISPATCH
+#undef GS_PLY_LAUNCH
     GS_CHECK_LAUNCH(pack ? "ply_pack" : "ply_unpack");
     return GS_OK;
 }

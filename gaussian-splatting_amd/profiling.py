@@ -20,14 +20,15 @@ def enable(only=None):
     _enabled = True
 
 
-def disable_and_collect():
-    """Mean milliseconds per call of every stage recorded since enable()."""
+def disable_and_collect(with_counts: bool = False):
+    """Mean milliseconds per call of every stage recorded since enable() (and, on request, the call counts)."""
     global _enabled
     _enabled = False
     torch.cuda.synchronize()
     out = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in _events.items() if v}
+    counts = {k: len(v) for k, v in _events.items() if v}
     _events.clear()
-    return out
+    return (out, counts) if with_counts else out
 
 
 class stage:

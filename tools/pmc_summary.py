@@ -8,6 +8,6 @@ for path in sys.argv[1:]:
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", path)
     for k, d in acc.items():
-        if not any(s in k for s in ("render", "preprocess", "radix", "duplicate", "scan", "identify")):
+        if not any(s in k for s in ("render", "preprocess", "radix", "duplicate", "scan", "identify", "adam", "ply", "l1_ssim", "knn")):
             continue
         print(k.ljust(42), " ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())))

@@ -74,6 +74,7 @@ def main():
                          "(parallel.SplatExchange); 'allreduce' = Gaussians replicated, gradients all-reduced")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 code path with several ranks on ONE GPU (timings meaningless)")
+    ap.add_argument("--forward-only", action="store_true", help="render only (implied by the 4K config)")
     ap.add_argument("--watchdog", type=float, default=0.0,
                     help="seconds after which a still-running bench dumps every thread's stack to stderr and exits")
     ap.add_argument("--force-dist", action="store_true",
@@ -115,7 +116,7 @@ def main():
     N, K, H, W = CONFIGS[args.config]
     t_eps = impl.DEFAULT_T_EPS if args.t_eps is None else args.t_eps
     scene = syn.make_scene(N, K, H, W, seed=0)
-    forward_only = "forward_only" in args.config
+    forward_only = "forward_only" in args.config or args.forward_only
     exchange = multi and args.parallel == "exchange" and not forward_only
     names = ("means3D", "shs", "opacities", "scales", "rotations")
 
@@ -126,7 +127,8 @@ def main():
             sh_degree=view.sh_degree, campos=view.campos.to(dev), prefiltered=False, debug=False)
 
     # N > 1: rank r renders view r of the SAME scene (camera jittered per view), one view per rank and step
-    views = [syn.jitter_view(scene, r) if multi else scene for r in range(world)]
+    # (forward-only 4K frames shard tile rows of ONE view instead: every rank gets the same camera)
+    views = [syn.jitter_view(scene, r) if (multi and not forward_only) else scene for r in range(world)]
     settings = make_settings(views[rank])
     G = scene.G.to(dev)
     rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
@@ -146,6 +148,13 @@ def main():
                 reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20))
 
     def step():
+        if forward_only and multi:
+            # large-frame inference: this rank renders its band of tile rows, rank 0 assembles the frame
+            with torch.no_grad():
+                band = par.render_band(settings, rank, world, t_eps=t_eps, means3D=params["means3D"], shs=params["shs"],
+                                       opacities=params["opacities"], scales=params["scales"],
+                                       rotations=params["rotations"])[0]
+                return par.gather_bands(band, H, dst=0)
         if forward_only:
             with torch.no_grad():
                 return rast(means3D=params["means3D"], means2D=None, shs=params["shs"], colors_precomp=None,
@@ -223,7 +232,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * W * H / (dt / args.steps) / 1e6
+    frames_per_step = 1 if (forward_only and multi) else world      # tile-row sharding splits ONE frame
+    value = frames_per_step * W * H / (dt / args.steps) / 1e6
 
     if rank == 0:
         # workload statistics for the byte model
@@ -261,17 +271,19 @@ def main():
                     "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4),
-                    "limiter": "VALU issue (SQ_ACTIVE_INST_VALU x4 / SIMD cycles = 92 % in render_bwd, "
-                               "profiles/r1c_pmc_sq_counters.txt); HBM accounting kept as the task prescribes"}
+                    "limiter": ("VALU issue (SQ_ACTIVE_INST_VALU x4 / SIMD cycles = 87 % in render_bwd, ~100 % in render_fwd, "
+                                "profiles/r1d_pmc_sq_counters.txt); HBM accounting kept as the task prescribes")
+                    if dominant.startswith("render") else "HBM / latency (see DESIGN.md section 4)"}
         out = {
             "metric": "Mpix/s fwd+bwd @3M Gaussians SH3" if args.config.startswith("config3") else "Mpix/s " + args.config, "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if (forward_only and multi) else "weak",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.config, "gaussians": N, "sh_coeffs": K, "width": W, "height": H,
                        "drawn": V, "tile_pairs": D, "t_eps": t_eps,
-                       "views_per_step": world,
-                       "parallelism": "single" if not multi else
+                       "views_per_step": frames_per_step,
+                       "parallelism": "single" if not multi else f"tile_rows{world}" if forward_only else
                        (f"views{world}+gaussians_sharded{world}(splat exchange)" if exchange else
                         f"views{world}+gaussians_replicated(grad all-reduce)")},
             "roofline": roofline,

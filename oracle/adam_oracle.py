@@ -31,7 +31,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
     """In place on float32 arrays; `step` is the 1-based count of this update.
 
     torch's CPU and GPU kernels round the same formulas differently; both forms were determined op by op
-    against torch 2.10 (tools/adam_forms_gpu*.py for the GPU; tests/test_adam_oracle.py pins the CPU form):
+    against torch 2.10 (tools/adam_forms_gpu.py, tools/adam_forms_gpu3.py for the GPU; tests/test_adam_oracle.py pins the CPU form):
                  CPU                                    GPU (what the reference runs when it trains on a GPU)
       lerp_      fma(w, g - m, m)                       fma(w, g - m, m)
       addcmul_   fma(a * g, g, v * beta2)               fma(a, g * g, v * beta2)

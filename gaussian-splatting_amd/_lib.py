@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgsplat_hip.so")
+# GSPLAT_LIB: another build of the same library (kernel experiments); default = the in-tree build
+LIB_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(_HERE, "lib", "libgsplat_hip.so")
 
 _vp, _i, _ll, _f, _sz, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 

@@ -29,7 +29,11 @@ namespace {
 
 constexpr int AD_MAX_GROUPS = 8;
 constexpr int AD_THREADS = 256;
-constexpr int AD_PER_THREAD = 8;
+#ifndef AD_PER_THREAD_DEF
+#define AD_PER_THREAD_DEF 8
+#endif
+constexpr int AD_PER_THREAD = AD_PER_THREAD_DEF;
+constexpr int AD_V4 = AD_PER_THREAD / 4;    // float4s per lane in the vector path
 constexpr int AD_BLOCK_ELEMS = AD_THREADS * AD_PER_THREAD;   // 2048 parameters per workgroup
 
 struct AdGroup {
@@ -108,10 +112,10 @@ __global__ __launch_bounds__(AD_THREADS) void adam_densify_kernel(const AdArgs a
     if (G.vec4) {
         // two float4 per lane, all loads issued before the first use.  vec4 == 2: the gradient is a
         // strided view, fetched as four dwords (a float4 of parameters may straddle two gradient rows)
-        float4 p[2], g[2], m[2], v[2];
-        long long e[2];
+        float4 p[AD_V4], g[AD_V4], m[AD_V4], v[AD_V4];
+        long long e[AD_V4];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < AD_V4; ++k) {
             e[k] = base + ((long long)k * AD_THREADS + threadIdx.x) * 4;
             if (e[k] < G.n_elems) {
                 p[k] = *reinterpret_cast<const float4*>(G.p + e[k]);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(AD_THREADS) void adam_densify_kernel(const AdArgs a
             }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < AD_V4; ++k) {
             if (e[k] < G.n_elems) {
                 adam_update(p[k].x, g[k].x, m[k].x, v[k].x, a, neg_step);
                 adam_update(p[k].y, g[k].y, m[k].y, v[k].y, a, neg_step);

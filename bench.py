@@ -274,6 +274,16 @@ def main():
                     "limiter": ("VALU issue (SQ_ACTIVE_INST_VALU x4 / SIMD cycles = 87 % in render_bwd, ~100 % in render_fwd, "
                                 "profiles/r1d_pmc_sq_counters.txt); HBM accounting kept as the task prescribes")
                     if dominant.startswith("render") else "HBM / latency (see DESIGN.md section 4)"}
+        # secondary bound: VALU issue rate of the render kernels, from the SQ counters under profiles/
+        try:
+            vt = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
+            if dominant in vt["kernels"] and args.config == "config3_garden_3M_sh3_1297x840" and args.t_eps is None:
+                rate = vt["kernels"][dominant]["valu_wave_insts"] / (stage_ms[dominant] * 1e-3)
+                roofline["valu"] = {"achieved_G_wave_insts_per_s": round(rate / 1e9, 1),
+                                    "peak_G_wave_insts_per_s": round(vt["peak_wave_insts_per_s"] / 1e9, 1),
+                                    "frac": round(rate / vt["peak_wave_insts_per_s"], 4), "source": vt["source"]}
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Mpix/s fwd+bwd @3M Gaussians SH3" if args.config.startswith("config3") else "Mpix/s " + args.config, "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

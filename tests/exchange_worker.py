@@ -50,6 +50,9 @@ def main():
     Gs = [(torch.rand(3, H, W, generator=gen) * 2 - 1).to(dev) for _ in range(world)]
     Gd = [(torch.rand(1, H, W, generator=gen) * 0.1).to(dev) for _ in range(world)]
 
+    if os.environ.get("EXCHANGE_VARIANT") == "precomp":
+        return precomp_variant(impl, par, base, sets, Gs, lo, hi, N, rank, world, dev)
+
     # ---- sharded step
     local = {k: getattr(base, k)[lo:hi].to(dev).clone().requires_grad_(True) for k in names}
     m2d = torch.zeros((world, hi - lo, 3), device=dev, requires_grad=True)
@@ -88,6 +91,39 @@ def main():
     assert ref.abs().max().item() > 0
     torch.cuda.synchronize()
     print(f"rank {rank}: OK", {k: f"{v:.1e}" for k, v in worst.items()}, f"means2D {e:.1e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def precomp_variant(impl, par, base, sets, Gs, lo, hi, N, rank, world, dev):
+    """colors_precomp + cov3D_precomp inputs, no means2D: the other argument combination of the rasterizer."""
+    g = torch.Generator().manual_seed(77)
+    colors = torch.rand(N, 3, generator=g)
+    Rm = torch.randn(N, 3, 3, generator=g) * base.scales.mean().item()
+    S = Rm @ Rm.transpose(1, 2) + 1e-6 * torch.eye(3)
+    cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous()
+    full = {"means3D": base.means3D, "colors": colors, "opacities": base.opacities, "cov": cov6}
+    loc = {k: v[lo:hi].to(dev).clone().requires_grad_(True) for k, v in full.items()}
+    ex = par.SplatExchange(hi - lo, device=dev)
+    image, radii, depth, alpha = ex.rasterize(sets, loc["means3D"], colors_precomp=loc["colors"],
+                                              opacities=loc["opacities"], cov3D_precomp=loc["cov"])
+    (image * Gs[rank]).sum().backward()
+    ref = {k: v.to(dev).clone().requires_grad_(True) for k, v in full.items()}
+    mine = None
+    for v in range(world):
+        out = impl.GaussianRasterizer(sets[v])(means3D=ref["means3D"], colors_precomp=ref["colors"],
+                                               opacities=ref["opacities"], cov3D_precomp=ref["cov"])
+        (out[0] * Gs[v]).sum().backward()
+        if v == rank:
+            mine = out[0].detach()
+    assert torch.equal(image, mine), "image differs from the single-GPU render"
+    worst = {}
+    for k in full:
+        want = ref[k].grad[lo:hi]
+        worst[k] = (loc[k].grad - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert worst[k] <= TOL_GRAD_REL, (k, worst[k])
+    torch.cuda.synchronize()
+    print(f"rank {rank}: OK", {k: f"{v:.1e}" for k, v in worst.items()}, flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

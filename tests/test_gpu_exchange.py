@@ -22,12 +22,13 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_splat_exchange_equals_single_gpu(world):
+@pytest.mark.parametrize("world,variant", [(2, "sh"), (3, "sh"), (2, "precomp")])
+def test_splat_exchange_equals_single_gpu(world, variant):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   EXCHANGE_VARIANT=variant)
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "exchange_worker.py")],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []

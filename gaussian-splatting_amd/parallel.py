@@ -11,6 +11,7 @@ the data path, only the final gather of the bands).
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -18,7 +19,7 @@ import torch.distributed as dist
 
 from .profiling import stage as _stage
 
-_DEBUG = bool(__import__("os").environ.get("GS_DEBUG_REDUCE"))
+_DEBUG = bool(os.environ.get("GS_DEBUG_REDUCE"))    # prints every bucket before its all-reduce
 
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:

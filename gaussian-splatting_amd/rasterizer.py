@@ -260,10 +260,12 @@ _readback = {}
 
 
 def _readback_slot(dev):
-    slot = _readback.get(dev.index)
+    """One pinned slot + event per (device, stream): frames queued on different streams do not share it."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    slot = _readback.get(key)
     if slot is None:
         slot = (torch.empty((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-        _readback[dev.index] = slot
+        _readback[key] = slot
     return slot
 
 

@@ -14,6 +14,11 @@
 //              exceeds the distance to the faces of the searched block of cells (exact termination test; faces
 //              on the grid boundary impose nothing).  A point still undecided after the last shell is "isolated":
 //   brute      one workgroup per isolated point scans all N points.
+//   dense      a uniform grid is quadratic inside cells that hold thousands of points (SfM clouds are that uneven): a
+//              point whose 27 cells hold more than KNN_DENSE_LIMIT points is set aside, and if there are any, all points
+//              are sorted by 63-bit Morton code (cubic cells of extent / 2^21) and every such point is answered
+//              adaptively: upper bound from its 16 neighbours in Morton order, then the 27 cells of the coarsest level
+//              whose cell edge still covers that bound (each cell = one contiguous code range, found by binary search).
 // Exact nearest neighbour; distances are computed from coordinate differences in fp32 (the reference's
 // cdist goes through |a|^2 + |b|^2 - 2 a.b for N > 25 and carries that form's cancellation error).
 #include "gsplat_common.h"
@@ -27,6 +32,9 @@ namespace {
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_MAX_RING = 3;
 constexpr int KNN_MAX_DIM = 1024;
+constexpr uint32_t KNN_DENSE_LIMIT = 1024;   // points in the 27 cells around a point beyond which it takes the Morton path
+constexpr int KNN_MORTON_BITS = 21;          // per axis
+constexpr uint32_t KNN_SCAN_LIMIT = 4096;    // ... or that would scan more than this many points over its shells
 
 __device__ __forceinline__ uint32_t f2ord(float f) {      // order-preserving float -> uint
     const uint32_t u = __float_as_uint(f);
@@ -110,15 +118,40 @@ __device__ __forceinline__ float scan_cell(const float4* __restrict__ sorted, co
 __global__ __launch_bounds__(KNN_THREADS) void knn_query_kernel(long long N, KnnGrid g, const float4* __restrict__ sorted,
                                                                  const uint2* __restrict__ ranges, float* __restrict__ out,
                                                                  uint32_t* __restrict__ hard_count,
-                                                                 uint32_t* __restrict__ hard_list) {
+                                                                 uint32_t* __restrict__ hard_list,
+                                                                 uint32_t* __restrict__ dense_count,
+                                                                 uint32_t* __restrict__ dense_list) {
     const long long r = (long long)blockIdx.x * KNN_THREADS + threadIdx.x;
     if (r >= N) return;
     const float4 p = sorted[r];
     int c[3];
     cell_of(g, p.x, p.y, p.z, c);
     const float pos[3] = {p.x, p.y, p.z};
+    {   // crowded neighbourhood: leave it to the adaptive (Morton) pass instead of scanning thousands of points here
+        uint32_t crowd = 0;
+        for (int cz = max(c[2] - 1, 0); cz <= min(c[2] + 1, g.dim[2] - 1); ++cz)
+            for (int cy = max(c[1] - 1, 0); cy <= min(c[1] + 1, g.dim[1] - 1); ++cy)
+                for (int cx = max(c[0] - 1, 0); cx <= min(c[0] + 1, g.dim[0] - 1); ++cx) {
+                    const uint2 rg = ranges[(cz * g.dim[1] + cy) * g.dim[0] + cx];
+                    crowd += rg.y - rg.x;
+                }
+        // one atomic per wave, not per point: in a cluster every lane of the wave lands here
+        const bool crowded = crowd > KNN_DENSE_LIMIT;
+        const uint64_t cm = __ballot(crowded);
+        if (cm) {
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)cm) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(dense_count, (uint32_t)__popcll(cm));
+            base = __shfl(base, leader);
+            if (crowded) {
+                dense_list[base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                return;
+            }
+        }
+    }
     float best = INFINITY;
     bool done = false;
+    uint32_t scanned = 0;
     for (int ring = 1; ring <= KNN_MAX_RING && !done; ++ring) {
         const int lo[3] = {max(c[0] - ring, 0), max(c[1] - ring, 0), max(c[2] - ring, 0)};
         const int hi[3] = {min(c[0] + ring, g.dim[0] - 1), min(c[1] + ring, g.dim[1] - 1), min(c[2] + ring, g.dim[2] - 1)};
@@ -131,7 +164,13 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_query_kernel(long long N, Knn
                         cx = min(c[0] + ring - 1, hi[0]);   // jump to the far face of the inner block
                         continue;
                     }
-                    best = scan_cell(sorted, ranges[(cz * g.dim[1] + cy) * g.dim[0] + cx], r, p.x, p.y, p.z, best);
+                    const uint2 rg = ranges[(cz * g.dim[1] + cy) * g.dim[0] + cx];
+                    scanned += rg.y - rg.x;
+                    if (scanned > KNN_SCAN_LIMIT) {      // a crowded cell further out: same treatment
+                        dense_list[atomicAdd(dense_count, 1u)] = (uint32_t)r;
+                        return;
+                    }
+                    best = scan_cell(sorted, rg, r, p.x, p.y, p.z, best);
                 }
             }
         // every point outside the searched block is farther than the nearest face that is not a grid boundary
@@ -182,10 +221,195 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_brute_kernel(long long N, con
     }
 }
 
+// ---- adaptive pass over Morton-sorted points (63-bit codes: 21 bits per axis, cubic cells of extent / 2^21 -- fine
+//      enough for float32 coordinates, so that even the tightest cluster spreads over many finest-level cells)
+__device__ __forceinline__ uint64_t spread3(uint64_t v) {       // 21 bits -> every third bit
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__device__ __forceinline__ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+
+struct KnnMorton {
+    float bmin[3];
+    float s0, inv_s0;      // finest cell edge = largest extent / 2^21
+};
+
+__device__ __forceinline__ void quantize(const KnnMorton& M, float x, float y, float z, uint32_t q[3]) {
+    const float p[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        q[a] = (uint32_t)fminf(fmaxf((p[a] - M.bmin[a]) * M.inv_s0, 0.0f), (float)((1 << KNN_MORTON_BITS) - 1));
+}
+
+__device__ __forceinline__ uint64_t code_of(const KnnMorton& M, const float* __restrict__ pts, uint32_t i) {
+    uint32_t q[3];
+    quantize(M, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], q);
+    return morton3(q[0], q[1], q[2]);
+}
+
+// the 63-bit code is sorted as two 32-bit words with the library's (key32, value32) sort: low word first, then stably
+// on the high word.  phase 0: key = low word of point i, value = i.  phase 1: key = high word of point order[i].
+__global__ __launch_bounds__(KNN_THREADS) void knn_morton_keys_kernel(long long N, KnnMorton M, int phase,
+                                                                       const float* __restrict__ pts,
+                                                                       const uint32_t* order,   // may alias ids (same index)
+                                                                       uint32_t* __restrict__ keys, uint32_t* ids) {
+    const long long i = (long long)blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t id = phase == 0 ? (uint32_t)i : order[i];
+    const uint64_t c = code_of(M, pts, id);
+    keys[i] = phase == 0 ? (uint32_t)c : (uint32_t)(c >> 32);
+    ids[i] = id;
+}
+
+// points and codes into Morton order + the inverse permutation (rank of every original index)
+__global__ __launch_bounds__(KNN_THREADS) void knn_morton_gather_kernel(long long N, KnnMorton M, const float* __restrict__ pts,
+                                                                         const uint32_t* __restrict__ order,
+                                                                         float4* __restrict__ sorted_m,
+                                                                         uint64_t* __restrict__ codes,
+                                                                         uint32_t* __restrict__ rank) {
+    const long long r = (long long)blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (r >= N) return;
+    const uint32_t i = order[r];
+    sorted_m[r] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __uint_as_float(i));
+    codes[r] = code_of(M, pts, i);
+    rank[i] = (uint32_t)r;
+}
+
+__device__ __forceinline__ uint32_t compact3(uint64_t v) {      // inverse of spread3
+    v &= 0x1249249249249249ull;
+    v = (v | (v >> 2)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v >> 4)) & 0x100F00F00F00F00Full;
+    v = (v | (v >> 8)) & 0x1F0000FF0000FFull;
+    v = (v | (v >> 16)) & 0x1F00000000FFFFull;
+    v = (v | (v >> 32)) & 0x1FFFFFull;
+    return (uint32_t)v;
+}
+
+__device__ __forceinline__ uint32_t lower_bound_in(const uint64_t* __restrict__ a, uint32_t lo, uint32_t hi, uint64_t key) {
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int KNN_STACK = 48;       // cells waiting to be opened (16 B each, per lane)
+constexpr uint32_t KNN_LEAF = 32;   // cells with at most this many points are scanned, larger ones split into 8
+
+// squared distance from p to the level-l cell with Morton prefix m (slack for the rounding of the quantisation; the last
+// cell of an axis also holds the points clamped into it, so its far face imposes nothing)
+__device__ __forceinline__ float cell_gap2(const KnnMorton& M, const float pos[3], uint64_t m, int l) {
+    const uint32_t cc[3] = {compact3(m), compact3(m >> 1), compact3(m >> 2)};
+    const float edge = M.s0 * (float)(1u << l);
+    const uint32_t last = (1u << (KNN_MORTON_BITS - l)) - 1u;
+    float gap2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = M.bmin[a] + (float)cc[a] * edge, hi = lo + edge;
+        float gdist = 0.0f;
+        if (pos[a] < lo) gdist = lo - pos[a];
+        else if (pos[a] > hi && cc[a] != last) gdist = pos[a] - hi;
+        gdist = fmaxf(gdist - 1e-3f * edge - 4.0f * M.s0, 0.0f);
+        gap2 += gdist * gdist;
+    }
+    return gap2;
+}
+
+// A crowded point: upper bound from its neighbours in Morton order, then a depth-first walk over the implicit octree
+// (a cell = one contiguous range of the sorted codes) from the 27 cells whose edge covers that bound, opening only
+// cells closer than the best distance so far -- a cluster of 10^5 points next to the query costs a few dozen cells.
+__global__ __launch_bounds__(KNN_THREADS) void knn_morton_query_kernel(long long N, KnnMorton M,
+                                                                        const float4* __restrict__ sorted_grid,
+                                                                        const uint32_t* __restrict__ dense_count,
+                                                                        const uint32_t* __restrict__ dense_list,
+                                                                        const uint64_t* __restrict__ codes,
+                                                                        const float4* __restrict__ sorted_m,
+                                                                        const uint32_t* __restrict__ rank,
+                                                                        float* __restrict__ out) {
+    const uint32_t h = blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (h >= *dense_count) return;
+    const float4 p = sorted_grid[dense_list[h]];
+    const uint32_t id = __float_as_uint(p.w);
+    const long long me = rank[id];
+    float best = INFINITY;
+    for (long long j = max(me - 8, 0ll); j <= min(me + 8, N - 1); ++j) {
+        const float4 q = sorted_m[j];
+        const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        best = (j != me && d < best) ? d : best;
+    }
+    if (best > 0.0f) {
+        // start level: cell edge s0 * 2^l >= the bound, so the true neighbour is in the 27 cells around p's
+        const float need = sqrtf(best) * 1.001f;
+        int l0 = 0;
+        float edge = M.s0;
+        while (l0 < KNN_MORTON_BITS && edge < need) { ++l0; edge *= 2.0f; }
+        uint32_t q[3];
+        quantize(M, p.x, p.y, p.z, q);
+        const int side = 1 << (KNN_MORTON_BITS - l0);
+        const int c[3] = {(int)(q[0] >> l0), (int)(q[1] >> l0), (int)(q[2] >> l0)};
+        const float pos[3] = {p.x, p.y, p.z};
+        uint64_t st_m[KNN_STACK];      // pending cells: Morton prefix,
+        uint2 st_r[KNN_STACK];         // range of the sorted codes,
+        int st_l[KNN_STACK];           // level
+        int sp = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int cc[3] = {c[0] + dx, c[1] + dy, c[2] + dz};
+                    if (cc[0] < 0 || cc[1] < 0 || cc[2] < 0 || cc[0] >= side || cc[1] >= side || cc[2] >= side) continue;
+                    const uint64_t m = morton3((uint32_t)cc[0], (uint32_t)cc[1], (uint32_t)cc[2]);
+                    if (cell_gap2(M, pos, m, l0) >= best) continue;
+                    const uint32_t lo = lower_bound_in(codes, 0, (uint32_t)N, m << (3 * l0));
+                    const uint32_t hi = l0 == KNN_MORTON_BITS ? (uint32_t)N : lower_bound_in(codes, lo, (uint32_t)N, (m + 1) << (3 * l0));
+                    // open this cell now (depth first), its pending children live on the stack
+                    st_m[0] = m; st_r[0] = make_uint2(lo, hi); st_l[0] = l0; sp = 1;
+                    while (sp > 0) {
+                        --sp;
+                        const uint64_t cm = st_m[sp];
+                        const uint2 cr = st_r[sp];
+                        const int cl = st_l[sp];
+                        if (cr.x >= cr.y || cell_gap2(M, pos, cm, cl) >= best) continue;
+                        if (cr.y - cr.x <= KNN_LEAF || cl == 0 || sp + 8 > KNN_STACK) {
+                            for (uint32_t j = cr.x; j < cr.y; ++j) {
+                                const float4 t = sorted_m[j];
+                                const float ex = t.x - p.x, ey = t.y - p.y, ez = t.z - p.z;
+                                const float d = ex * ex + ey * ey + ez * ez;
+                                best = ((long long)j != me && d < best) ? d : best;
+                            }
+                            continue;
+                        }
+                        // split: the 8 children are consecutive sub-ranges of [lo, hi)
+                        uint32_t b = cr.x;
+#pragma unroll 1
+                        for (uint64_t k = 0; k < 8; ++k) {
+                            const uint64_t km = (cm << 3) | k;
+                            const uint32_t e = k == 7 ? cr.y : lower_bound_in(codes, b, cr.y, (km + 1) << (3 * (cl - 1)));
+                            if (e > b) { st_m[sp] = km; st_r[sp] = make_uint2(b, e); st_l[sp] = cl - 1; ++sp; }
+                            b = e;
+                        }
+                    }
+                }
+    }
+    out[id] = best;
+}
+
+__global__ void knn_fill_kernel(long long N, float v, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = v;
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct KnnWs {
-    size_t box, hard_count, keys_a, keys_b, ids_a, ids_b, sorted, ranges, hard_list, sort_ws, total;
+    size_t box, hard_count, dense_count, keys_a, keys_b, ids_a, ids_b, sorted, ranges, hard_list, dense_list, sorted_m, codes, sort_ws, total;
 };
 
 KnnWs knn_layout(long long N) {
@@ -194,13 +418,17 @@ KnnWs knn_layout(long long N) {
     size_t o = 0;
     w.box = o; o += 256;
     w.hard_count = o; o += 256;
+    w.dense_count = o; o += 256;
     w.keys_a = o; o += align256(4 * n);
     w.keys_b = o; o += align256(4 * n);
     w.ids_a = o; o += align256(4 * n);
     w.ids_b = o; o += align256(4 * n);
     w.sorted = o; o += align256(16 * n);
-    w.ranges = o; o += align256(8 * (2 * n + 64));        // the grid never has more than 2 N + 64 cells
+    w.ranges = o; o += align256(8 * (2 * n + 64));        // the grid never has more than 2 N + 64 cells (reused: Morton ranks)
     w.hard_list = o; o += align256(4 * n);
+    w.dense_list = o; o += align256(4 * n);
+    w.sorted_m = o; o += align256(16 * n);
+    w.codes = o; o += align256(8 * n);
     w.sort_ws = o; o += align256(gs_sort_workspace_bytes(N));
     w.total = o;
     return w;
@@ -213,7 +441,7 @@ extern "C" size_t gs_nearest_dist2_workspace_bytes(long long N) { return knn_lay
 extern "C" int gs_nearest_dist2(long long N, const float* points, float* dist2, void* workspace, size_t workspace_bytes,
                                 int* stats, void* stream_) {
     GS_REQUIRE(N >= 0 && N < (1ll << 31), "N outside 0..2^31");
-    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
     if (N == 0) return GS_OK;
     GS_REQUIRE(points && dist2 && workspace, "null argument");
     GS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
@@ -226,7 +454,9 @@ extern "C" int gs_nearest_dist2(long long N, const float* points, float* dist2, 
     // ---- bounding box (the one host round trip: the grid is chosen from it)
     const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     GS_CHECK_HIP(hipMemcpyAsync(box, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    uint32_t* dense_count = (uint32_t*)(ws + w.dense_count);
     GS_CHECK_HIP(hipMemsetAsync(hard_count, 0, 4, stream));
+    GS_CHECK_HIP(hipMemsetAsync(dense_count, 0, 4, stream));
     const int bbox_blocks = (int)(gs_div_up(N, KNN_THREADS) < 1024 ? gs_div_up(N, KNN_THREADS) : 1024);
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(bbox_blocks), dim3(KNN_THREADS), 0, stream, N, points, box);
     GS_CHECK_LAUNCH("knn_bbox");
@@ -242,6 +472,11 @@ extern "C" int gs_nearest_dist2(long long N, const float* points, float* dist2, 
     }
     // cell size: about N / 2 cells in total with every axis between 1 and KNN_MAX_DIM cells (bisection on the size)
     const double emax = fmax(ext[0], fmax(ext[1], ext[2]));
+    if (emax == 0.0) {      // every point at the same place: distance 0 (a single point: +inf, as in the reference)
+        hipLaunchKernelGGL(knn_fill_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, stream, N, N > 1 ? 0.0f : INFINITY, dist2);
+        GS_CHECK_LAUNCH("knn_fill");
+        return GS_OK;
+    }
     double cell = 1.0;
     if (emax > 0.0) {
         const double target = fmax(1.0, (double)N / 2.0);
@@ -300,16 +535,46 @@ extern "C" int gs_nearest_dist2(long long N, const float* points, float* dist2, 
     hipLaunchKernelGGL(knn_gather_kernel, grid, block, 0, stream, N, points, order, sorted);
     GS_CHECK_LAUNCH("knn_gather");
     uint32_t* hard_list = (uint32_t*)(ws + w.hard_list);
+    uint32_t* dense_list = (uint32_t*)(ws + w.dense_list);
     hipLaunchKernelGGL(knn_query_kernel, grid, block, 0, stream, N, g, sorted, (const uint2*)ranges, dist2, hard_count,
-                       hard_list);
+                       hard_list, dense_count, dense_list);
     GS_CHECK_LAUNCH("knn_query");
     hipLaunchKernelGGL(knn_brute_kernel, dim3(1024), dim3(KNN_THREADS), 0, stream, N, sorted, hard_count, hard_list, dist2);
     GS_CHECK_LAUNCH("knn_brute");
+    // ---- crowded neighbourhoods (second host round trip: how many, if any)
+    uint32_t counts[2] = {0, 0};
+    GS_CHECK_HIP(hipMemcpyAsync(&counts[0], hard_count, 4, hipMemcpyDeviceToHost, stream));
+    GS_CHECK_HIP(hipMemcpyAsync(&counts[1], dense_count, 4, hipMemcpyDeviceToHost, stream));
+    GS_CHECK_HIP(hipStreamSynchronize(stream));
+    if (counts[1] > 0) {
+        KnnMorton M;
+        for (int a = 0; a < 3; ++a) M.bmin[a] = g.bmin[a];
+        M.s0 = (float)(emax / (double)(1 << KNN_MORTON_BITS) * (1.0 + 1e-6));
+        M.inv_s0 = 1.0f / M.s0;
+        hipLaunchKernelGGL(knn_morton_keys_kernel, grid, block, 0, stream, N, M, 0, points, (const uint32_t*)nullptr, keys_a,
+                           ids_a);
+        GS_CHECK_LAUNCH("knn_morton_keys");
+        rc = gs_sort_pairs(N, nullptr, 0, 32, keys_a, ids_a, keys_b, ids_b, ws + w.sort_ws, gs_sort_workspace_bytes(N), &in_b,
+                           stream);
+        if (rc) return rc;
+        // high words in the order of the low-word sort, back into the (a) buffers the sort reads from
+        hipLaunchKernelGGL(knn_morton_keys_kernel, grid, block, 0, stream, N, M, 1, points, in_b ? ids_b : ids_a, keys_a, ids_a);
+        GS_CHECK_LAUNCH("knn_morton_keys");
+        rc = gs_sort_pairs(N, nullptr, 0, 3 * KNN_MORTON_BITS - 32, keys_a, ids_a, keys_b, ids_b, ws + w.sort_ws,
+                           gs_sort_workspace_bytes(N), &in_b, stream);
+        if (rc) return rc;
+        const uint32_t* morder = in_b ? ids_b : ids_a;
+        float4* sorted_m = (float4*)(ws + w.sorted_m);
+        uint64_t* codes = (uint64_t*)(ws + w.codes);
+        uint32_t* rank = ranges;                       // the grid's cell table is no longer needed
+        hipLaunchKernelGGL(knn_morton_gather_kernel, grid, block, 0, stream, N, M, points, morder, sorted_m, codes, rank);
+        GS_CHECK_LAUNCH("knn_morton_gather");
+        hipLaunchKernelGGL(knn_morton_query_kernel, dim3(gs_div_up(counts[1], KNN_THREADS)), block, 0, stream, N, M, sorted,
+                           dense_count, dense_list, codes, sorted_m, rank, dist2);
+        GS_CHECK_LAUNCH("knn_morton_query");
+    }
     if (stats) {
-        uint32_t nh = 0;
-        GS_CHECK_HIP(hipMemcpyAsync(&nh, hard_count, 4, hipMemcpyDeviceToHost, stream));
-        GS_CHECK_HIP(hipStreamSynchronize(stream));
-        stats[0] = g.dim[0]; stats[1] = g.dim[1]; stats[2] = g.dim[2]; stats[3] = (int)nh;
+        stats[0] = g.dim[0]; stats[1] = g.dim[1]; stats[2] = g.dim[2]; stats[3] = (int)counts[0]; stats[4] = (int)counts[1];
     }
     return GS_OK;
 }

@@ -28,11 +28,11 @@ def distCUDA2(points: torch.Tensor, return_stats: bool = False):
         nbytes = lib.gs_nearest_dist2_workspace_bytes(N)
         ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
         shift = (-ws.data_ptr()) % 256
-        stats = (C.c_int * 4)()
+        stats = (C.c_int * 5)()
         _lib.check(lib.gs_nearest_dist2(N, C.c_void_p(pts.data_ptr()) if N else None,
                                         C.c_void_p(out.data_ptr()) if N else None,
                                         C.c_void_p(ws.data_ptr() + shift), nbytes, stats if return_stats else None,
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gs_nearest_dist2")
     if return_stats:
-        return out, {"grid": (stats[0], stats[1], stats[2]), "isolated": stats[3]}
+        return out, {"grid": (stats[0], stats[1], stats[2]), "isolated": stats[3], "crowded": stats[4]}
     return out

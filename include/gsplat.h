@@ -241,9 +241,11 @@ int gs_ply_pack(const GsPlyLayout* layout, void* records, const float* xyz, cons
  * (scene/gaussian_model.py:729-746: N x N torch.cdist, diagonal = inf, row minimum, squared; out of memory
  * at 100 k points), which initialises the scales from the SfM cloud (:212-217).  points (N,3) fp32 device,
  * dist2 (N,) fp32 device; a single point gets +inf, as in the reference.  Uniform grid + the library's radix
- * sort, exact; O(N) memory (workspace: 256-byte aligned device memory).  Synchronises the stream once (reads
- * the bounding box back to size the grid).  stats (host, 4 ints, may be NULL; a second sync when given):
- * grid dims x y z and the number of isolated points settled by the brute-force pass.
+ * sort, exact; O(N) memory (workspace: 256-byte aligned device memory).  Points in crowded neighbourhoods
+ * (more than 1024 points in their 27 cells) are answered by an adaptive pass over Morton-sorted points, so the
+ * cost stays near-linear on clouds of very uneven density.  Synchronises the stream twice (reads the bounding
+ * box back to size the grid, and the number of crowded points).  stats (host, 5 ints, may be NULL): grid dims
+ * x y z, the number of isolated points settled by the brute-force pass, the number answered by the adaptive pass.
  */
 size_t gs_nearest_dist2_workspace_bytes(long long N);
 int gs_nearest_dist2(long long N, const float* points, float* dist2, void* workspace, size_t workspace_bytes,

@@ -62,12 +62,28 @@ def test_outliers_duplicates_planar_and_offsets(knn):
     _check(knn.distCUDA2(line.cuda()), line.numpy(), knn_oracle.nearest_dist2(line.numpy()))
 
 
+@pytest.mark.parametrize("n,frac,sigma", [(200000, 0.9, 0.01), (100000, 0.99, 0.001), (150000, 0.5, 0.1)])
+def test_very_uneven_density_takes_the_adaptive_pass(knn, n, frac, sigma):
+    """SfM-like clouds: most points in a few tight clusters inside a large box.  The uniform grid alone is quadratic
+    there; crowded points go through the Morton-ordered adaptive pass (stats["crowded"]) and stay exact."""
+    g = torch.Generator().manual_seed(int(1000 * sigma) + n)
+    nd = int(n * frac)
+    centres = (torch.rand(10, 3, generator=g) - 0.5) * 20
+    dense = centres[torch.randint(0, 10, (nd,), generator=g)] + torch.randn(nd, 3, generator=g) * sigma
+    p = torch.cat([dense, (torch.rand(n - nd, 3, generator=g) - 0.5) * 20])
+    p[:50] = p[50:100]                                              # duplicates inside the crowded part
+    d, st = knn.distCUDA2(p.cuda(), return_stats=True)
+    assert st["crowded"] > 0.3 * nd
+    _check(d, p.numpy(), knn_oracle.nearest_dist2_kdtree(p.numpy()))
+    assert float(d[:100].max()) == 0.0
+
+
 def test_large_uniform_vs_kdtree_and_errors(knn):
     g = torch.Generator().manual_seed(11)
     p = torch.rand(400000, 3, generator=g) * torch.tensor([20.0, 12.0, 6.0])
     d, st = knn.distCUDA2(p.cuda(), return_stats=True)
     _check(d, p.numpy(), knn_oracle.nearest_dist2_kdtree(p.numpy()))
-    assert st["isolated"] < 100
+    assert st["isolated"] < 100 and st["crowded"] == 0
     assert knn.distCUDA2(torch.zeros(0, 3).cuda()).shape == (0,)
     with pytest.raises(RuntimeError):
         knn.distCUDA2(torch.zeros(4, 3))

@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 R = importlib.import_module("gaussian-splatting_amd.rasterizer")
 syn = importlib.import_module("gaussian-splatting_amd.synthetic")
 impl = importlib.import_module("gaussian-splatting_amd")

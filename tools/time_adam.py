@@ -1,6 +1,6 @@
 """Times gs_adam_densify_step on 3 M Gaussians' worth of parameters (library chosen by GSPLAT_LIB)."""
 import importlib, os, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 impl = importlib.import_module("gaussian-splatting_amd")
 dev = torch.device("cuda:0")
 N, K = 3_000_000, 16

@@ -141,11 +141,21 @@ def _scene_settings(dgr, sc, dev):
         sh_degree=sc.sh_degree, campos=sc.campos.to(dev), prefiltered=False, debug=False)
 
 
-@pytest.mark.parametrize("N,K,H,W,seed", [(20000, 16, 300, 420, 3), (60000, 4, 203, 317, 4)])
-def test_midsize_vs_oracle(dgr, oracle, N, K, H, W, seed):
-    """Sizes the reference cannot reach in reasonable time; the pinned oracle is the checker."""
+@pytest.mark.parametrize("N,K,H,W,seed,clustered", [(20000, 16, 300, 420, 3, False), (60000, 4, 203, 317, 4, False),
+                                                    (40000, 16, 240, 320, 5, True)])
+def test_midsize_vs_oracle(dgr, oracle, N, K, H, W, seed, clustered):
+    """Sizes the reference cannot reach in reasonable time; the pinned oracle is the checker.
+    clustered: 70 % of the Gaussians pulled into two small regions -- a few tiles carry lists ~30x the mean, most
+    pixels there saturate early, other tiles are nearly empty (what a real capture looks like next to the 8d scene)."""
     syn = importlib.import_module("gaussian-splatting_amd.synthetic")
     sc = syn.make_scene(N, K, H, W, seed=seed)
+    if clustered:
+        g0 = torch.Generator().manual_seed(seed)
+        m = torch.rand(N, generator=g0) < 0.7
+        centres = torch.tensor([[0.6, -0.3, 4.0], [-1.0, 0.5, 6.0]])
+        pick = centres[torch.randint(0, 2, (N,), generator=g0)]
+        sc.means3D = torch.where(m[:, None], pick + 0.15 * torch.randn(N, 3, generator=g0), sc.means3D).contiguous()
+        sc.opacities = torch.where(m[:, None], sc.opacities * 0.3, sc.opacities).contiguous()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(99)
     G_C = sc.G

@@ -368,7 +368,7 @@ def bench_knn(points, dev, iters=5):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     return {"ms": round(ms, 3), "points": points.shape[0], "Mpoints_per_s": round(points.shape[0] / ms / 1e3, 1),
-            "grid": list(st["grid"]), "isolated_points": st["isolated"],
+            "grid": list(st["grid"]), "isolated_points": st["isolated"], "crowded_points": st["crowded"],
             "note": "wall time incl. the bounding-box read-back; exact 1-NN, O(N) memory"}
 
 

@@ -32,9 +32,9 @@ namespace {
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_MAX_RING = 3;
 constexpr int KNN_MAX_DIM = 1024;
-constexpr uint32_t KNN_DENSE_LIMIT = 1024;   // points in the 27 cells around a point beyond which it takes the Morton path
+constexpr uint32_t KNN_DENSE_LIMIT = 4096;   // points in the 27 cells around a point beyond which it takes the Morton path
 constexpr int KNN_MORTON_BITS = 21;          // per axis
-constexpr uint32_t KNN_SCAN_LIMIT = 4096;    // ... or that would scan more than this many points over its shells
+constexpr uint32_t KNN_SCAN_LIMIT = 16384;   // ... or that would scan more than this many points over its shells
 
 __device__ __forceinline__ uint32_t f2ord(float f) {      // order-preserving float -> uint
     const uint32_t u = __float_as_uint(f);

@@ -242,7 +242,7 @@ int gs_ply_pack(const GsPlyLayout* layout, void* records, const float* xyz, cons
  * at 100 k points), which initialises the scales from the SfM cloud (:212-217).  points (N,3) fp32 device,
  * dist2 (N,) fp32 device; a single point gets +inf, as in the reference.  Uniform grid + the library's radix
  * sort, exact; O(N) memory (workspace: 256-byte aligned device memory).  Points in crowded neighbourhoods
- * (more than 1024 points in their 27 cells) are answered by an adaptive pass over Morton-sorted points, so the
+ * (more than 4096 points in their 27 cells) are answered by an adaptive pass over Morton-sorted points, so the
  * cost stays near-linear on clouds of very uneven density.  Synchronises the stream twice (reads the bounding
  * box back to size the grid, and the number of crowded points).  stats (host, 5 ints, may be NULL): grid dims
  * x y z, the number of isolated points settled by the brute-force pass, the number answered by the adaptive pass.

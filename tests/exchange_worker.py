@@ -35,6 +35,9 @@ def main():
     base = syn.make_scene(N, K, H, W, seed=3)
     # uneven shards: rank r owns [bounds[r], bounds[r+1])
     bounds = [0] + [int(N * (r + 1) / world * (0.8 if r + 1 < world else 1.0)) for r in range(world)]
+    if os.environ.get("EXCHANGE_VARIANT") == "empty_shard":       # the last rank owns nothing (after heavy pruning, say)
+        bounds = [0] + [N] * world
+        bounds[1:world] = [int(N * (r + 1) / (world - 1)) if world > 2 else N for r in range(world - 1)]
     lo, hi = bounds[rank], bounds[rank + 1]
     names = ("means3D", "shs", "opacities", "scales", "rotations")
     views = [syn.jitter_view(base, v) for v in range(world)]
@@ -80,6 +83,15 @@ def main():
     assert torch.equal(depth, ref_out[2]) and torch.equal(alpha, ref_out[3])
     assert torch.equal(radii, torch.stack(ref_radii))
     worst = {}
+    if hi == lo:                                   # empty shard: empty gradients of the right shapes, nothing else
+        for k in names:
+            assert local[k].grad is not None and local[k].grad.shape == local[k].shape
+        assert m2d.grad.shape == (world, 0, 3)
+        torch.cuda.synchronize()
+        print(f"rank {rank}: OK (empty shard)", flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for k in names:
         ref = full[k].grad[lo:hi]
         err = (local[k].grad - ref).abs().max().item()

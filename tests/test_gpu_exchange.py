@@ -22,7 +22,7 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,variant", [(2, "sh"), (3, "sh"), (2, "precomp")])
+@pytest.mark.parametrize("world,variant", [(2, "sh"), (3, "sh"), (2, "precomp"), (2, "empty_shard")])
 def test_splat_exchange_equals_single_gpu(world, variant):
     port = _free_port()
     procs = []
@@ -40,5 +40,5 @@ def test_splat_exchange_equals_single_gpu(world, variant):
             if p.poll() is None:
                 p.kill()
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+        assert p.returncode == 0, f"rank {r} failed:\n" + "\n".join(f"--- rank {k} ---\n{x[-2500:]}" for k, x in enumerate(outs))
         assert f"rank {r}: OK" in o

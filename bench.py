@@ -306,9 +306,9 @@ def main():
             if exchange:
                 n_loc = params["means3D"].shape[0]
                 out["exchange_bytes_per_rank_and_step"] = {
-                    "forward_out": (world - 1) * n_loc * 60, "backward_in": (world - 1) * n_loc * 64,
+                    "forward_out": (world - 1) * n_loc * 60, "backward_in": (world - 1) * n_loc * 4 * impl.rasterizer.grad_row_floats(),
                     "note": "60 B (record 48 + depth key 4 + box 8) per local Gaussian and remote view out, "
-                            "64 B gradient row per local Gaussian and remote view back"}
+                            "48 B gradient row per local Gaussian and remote view back"}
         if world == 1 and not forward_only:
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
                                 "adam_densify_step": bench_adam(impl, params, radii, dev),

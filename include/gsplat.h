@@ -121,7 +121,7 @@ int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32
 
 /*
  * Backward of gs_render_fwd (the reference gets it from torch autograd).  g_image (3,H,W),
- * g_depth / g_alpha (H,W) optional.  grad_rows (N x 16 floats, 16-byte aligned) must be zero on
+ * g_depth / g_alpha (H,W) optional.  grad_rows (N x gs_grad_row_floats() = 12 floats, 16-byte aligned) must be zero on
  * entry and receives, per Gaussian: [0,1] d/d screen mean (pixels), [2] d/d conic a, [3] d/d each
  * off-diagonal conic entry, [4] d/d conic d, [5] d/d opacity, [6..8] d/d rgb, [9] d/d depth.
  * t_eps must equal the forward's.

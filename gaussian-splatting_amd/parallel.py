@@ -248,18 +248,27 @@ class _RasterizeSharded(torch.autograd.Function):
             # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, 12)
             rows_mine = torch.empty((world * max(n, 1), R.grad_row_floats()), dtype=torch.float32, device=dev)[:world * n]
             with _stage("exchange_bwd"):
-                _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group)
+                w_rows = _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group, True)
             rows_mine = rows_mine.view(world, n, R.grad_row_floats())
-            # 5. chain rule through my shard's projection into each view, summed over the views
+            # 5. chain rule through my shard's projection into each view, summed over the views.  My own view's rows
+            # never travel: its launch reads them where render_backward left them and runs while the all-to-all is
+            # in flight; it writes, the others add in place (accumulate flag of the C-ABI).
+            off = int(sum(counts[:rank]))
             acc = None
-            g_m2d = []
-            for v in range(world):       # view 0 writes, the others add in place (accumulate flag of the C-ABI)
+            g_m2d = {}
+            for v in [rank] + [u for u in range(world) if u != rank]:
+                if v != rank and w_rows is not None:
+                    with _stage("exchange_bwd_wait"):
+                        _wait(w_rows)
+                    w_rows = None
                 g = R.preprocess_backward(views[v], means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
-                                          radii[v], rows_mine[v], needs, (n, 3) if per_view_means2D else None,
-                                          accumulate_into=acc)
+                                          radii[v], rows[off:off + n] if v == rank else rows_mine[v], needs,
+                                          (n, 3) if per_view_means2D else None, accumulate_into=acc)
                 if per_view_means2D and needs[1]:
-                    g_m2d.append(g[1])
+                    g_m2d[v] = g[1]
                 acc = g
+            _wait(w_rows)        # world 1: nothing waited above
+            g_m2d = [g_m2d[v] for v in range(world)] if g_m2d else []
             acc = list(acc)
             if needs[1] and ctx.means2D_shape is not None:
                 acc[1] = torch.stack(g_m2d) if per_view_means2D else \

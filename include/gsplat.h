@@ -40,7 +40,7 @@ extern "C" {
 int gs_version(void);            /* 100 = 0.1.0 */
 const char* gs_last_error(void); /* message of this thread's last failing call */
 int gs_tile_size(void);          /* 16: tile edge used by keys and ranges */
-int gs_grad_row_floats(void);    /* 16: floats per per-Gaussian gradient row (see gs_render_bwd) */
+int gs_grad_row_floats(void);    /* 12: floats per per-Gaussian gradient row (see gs_render_bwd) */
 
 /*
  * Per-Gaussian forward stage.  Replaces GaussianRasterizer.forward's vectorised prologue

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Randomised parity hunt: the HIP path against the CPU oracle (oracle/gs_oracle.c) on small adversarial scenes.
+
+Each case draws sizes, the input variant (SH / precomputed colours, scales+rotations / precomputed covariance), a
+rotated and translated camera, a background, and a mix of awkward Gaussians (behind the camera, on the near limit,
+far off screen, screen-filling, needle-thin, almost transparent, almost opaque, unnormalised quaternions), then
+compares image / depth / alpha / radii / every gradient with the tolerances of tests/util.py.  Test infrastructure
+(it drives the oracle); the seeds that matter are frozen in tests/test_gpu_fuzz.py.
+
+usage: python tools/fuzz_parity.py [first_seed] [cases] [t_eps]
+"""
+import importlib
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def make_case(seed):
+    """-> dict of numpy inputs (float32) + meta; deterministic in `seed`."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    r = np.random.RandomState(seed)
+    N = int(r.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000]))
+    H = int(r.choice([1, 5, 16, 17, 31, 48, 90, 133, 200]))
+    W = int(r.choice([1, 3, 16, 33, 64, 95, 160, 211]))
+    K = int(r.choice([1, 4, 9, 16]))
+    deg = int(r.randint(0, int(round(math.sqrt(K)))))          # any degree the coefficients allow
+    sc = syn.make_scene(N, K, H, W, seed=seed, sh_degree=deg)
+    m, s, q, o = sc.means3D.numpy().copy(), sc.scales.numpy().copy(), sc.rotations.numpy().copy(), sc.opacities.numpy().copy()
+    pick = lambda frac: r.rand(N) < frac  # noqa: E731
+    m[pick(0.05), 2] *= -1.0                                      # behind the camera
+    near = pick(0.05); m[near, 2] = 0.2 + r.rand(int(near.sum())).astype(np.float32) * 0.02 - 0.01   # noqa: E702
+    m[pick(0.05), 0] *= 6.0                                       # far off screen
+    big = pick(0.03); s[big] *= 40.0                              # noqa: E702  screen-filling
+    thin = pick(0.05); s[thin, int(r.randint(3))] *= 1e-4         # noqa: E702  needles / discs
+    s[pick(0.03)] *= 1e-3                                         # sub-pixel: the 0.3 dilation dominates
+    o[pick(0.05)] = 1e-4
+    o[pick(0.05)] = 0.99
+    q *= (0.25 + 2.0 * r.rand(N, 1)).astype(np.float32)           # the reference does not normalise
+    # camera: rotation by small Euler angles and a translation
+    ax, ay, az = (r.rand(3) - 0.5) * np.array([0.5, 0.5, 2.0])
+    Rx = np.array([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+    Ry = np.array([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
+    Rz = np.array([[math.cos(az), -math.sin(az), 0], [math.sin(az), math.cos(az), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+    c = (r.randn(3) * 0.3)
+    V = np.eye(4)
+    V[:3, :3] = R
+    V[:3, 3] = -R @ c
+    P, tanx, tany = syn.pinhole(H, W)
+    V = V.astype(np.float32)
+    case = dict(seed=seed, N=N, H=H, W=W, K=K, deg=deg, tanfovx=tanx, tanfovy=tany,
+                viewmatrix=V, projmatrix=(P.numpy() @ V).astype(np.float32), campos=c.astype(np.float32),
+                bg=r.rand(3).astype(np.float32) * float(r.rand() < 0.5),
+                means3D=m, opacities=o, scales=None, rotations=None, cov3D_precomp=None, shs=None, colors_precomp=None)
+    if r.rand() < 0.25:
+        # precomputed covariance: upper triangle of (R S)(R S)^T from the same scales and quaternions
+        w, x, y, z = (q[:, i].astype(np.float64) for i in range(4))
+        Rq = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                       2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                       2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(N, 3, 3)
+        M = Rq * s[:, None, :].astype(np.float64)
+        S = M @ M.transpose(0, 2, 1)
+        case["cov3D_precomp"] = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]],
+                                         axis=1).astype(np.float32)
+    else:
+        case["scales"], case["rotations"] = s, q
+    if r.rand() < 0.25:
+        case["colors_precomp"] = r.rand(N, 3).astype(np.float32)
+    else:
+        case["shs"] = sc.shs.numpy().copy()
+    case["G_C"] = (r.rand(3, H, W).astype(np.float32) * 2 - 1)
+    case["G_Z"] = (r.rand(1, H, W).astype(np.float32) * 2 - 1) * 0.1
+    case["G_A"] = (r.rand(1, H, W).astype(np.float32) * 2 - 1)
+    return case
+
+
+INPUTS = ("means3D", "opacities", "scales", "rotations", "cov3D_precomp", "shs", "colors_precomp")
+
+
+def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None):
+    """Raises AssertionError on a mismatch; returns the worst relative gradient error."""
+    from util import TOL_DEPTH, TOL_GRAD_REL, TOL_IMAGE, check_grad
+    dev = torch.device("cuda:0")
+    H, W = case["H"], case["W"]
+    outs, grads, geom = oracle.forward_backward(
+        H, W, case["deg"], case["viewmatrix"], case["projmatrix"], case["campos"], case["bg"], case["means3D"],
+        case["opacities"], scales=case["scales"], rotations=case["rotations"], cov3D_precomp=case["cov3D_precomp"],
+        shs=case["shs"], colors_precomp=case["colors_precomp"], G_C=case["G_C"], G_Z=case["G_Z"], G_A=case["G_A"])
+    t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    inp = {k: (None if case[k] is None else t(case[k]).requires_grad_(True)) for k in INPUTS}
+    settings = dgr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=case["tanfovx"], tanfovy=case["tanfovy"], bg=t(case["bg"]),
+        scale_modifier=1.0, viewmatrix=t(case["viewmatrix"]), projmatrix=t(case["projmatrix"]), sh_degree=case["deg"],
+        campos=t(case["campos"]), prefiltered=False, debug=False)
+    rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
+    means2D = torch.zeros((case["N"], 3), device=dev, requires_grad=True)
+    image, radii, depth, alpha = rast(means3D=inp["means3D"], means2D=means2D, shs=inp["shs"],
+                                      colors_precomp=inp["colors_precomp"], opacities=inp["opacities"],
+                                      scales=inp["scales"], rotations=inp["rotations"],
+                                      cov3D_precomp=inp["cov3D_precomp"])
+    ((image * t(case["G_C"])).sum() + (depth * t(case["G_Z"])).sum() + (alpha * t(case["G_A"])).sum()).backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), geom.radii), "radii differ"
+    for name, got, ref, tol in (("image", image, outs["render"], TOL_IMAGE), ("alpha", alpha, outs["alpha"], TOL_IMAGE),
+                                ("depth", depth, outs["depth"], TOL_DEPTH)):
+        got = got.detach().cpu().numpy()
+        assert np.isfinite(got).all(), f"{name}: non-finite"
+        err = np.abs(got - ref).max()
+        assert err <= tol, f"{name}: max-abs err {err:.3e} > {tol}"
+    worst = 0.0
+    for k in INPUTS:
+        if inp[k] is not None:
+            assert np.isfinite(grads[k]).all(), f"oracle gradient of {k} is not finite: not a usable case"
+            worst = max(worst, check_grad(f"d_{k}", inp[k].grad.cpu().numpy(), grads[k],
+                                              rel=grad_rel or TOL_GRAD_REL))
+    return worst
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    t_eps = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+    import diff_gaussian_rasterization as dgr
+    from oracle import oracle
+    oracle.build()
+    bad = 0
+    for seed in range(first, first + cases):
+        case = make_case(seed)
+        tag = (f"seed {seed}: N={case['N']} {case['W']}x{case['H']} K={case['K']} deg={case['deg']} "
+               f"{'cov' if case['cov3D_precomp'] is not None else 'sr'}/{'rgb' if case['colors_precomp'] is not None else 'sh'}")
+        try:
+            worst = run_case(case, dgr, oracle, t_eps)
+            print(f"ok   {tag} worst grad err {worst:.2e}", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"FAIL {tag}: {e}", flush=True)
+    print(f"{cases - bad} of {cases} cases within tolerance", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -309,6 +309,30 @@ def main():
                     "forward_out": (world - 1) * n_loc * 60, "backward_in": (world - 1) * n_loc * 4 * impl.rasterizer.grad_row_floats(),
                     "note": "60 B (record 48 + depth key 4 + box 8) per local Gaussian and remote view out, "
                             "48 B gradient row per local Gaussian and remote view back"}
+        if world == 1 and not forward_only and t_eps > 0:
+            # the same frame without early termination (t_eps = 0: the reference's exact semantics, the mode the
+            # parity tests pin); reported beside the headline, which runs at the library's default t_eps
+            rast_exact = dgr.GaussianRasterizer(settings, t_eps=0.0)
+
+            def exact_step():
+                for p in params.values():
+                    p.grad = None
+                m2 = torch.zeros_like(params["means3D"], requires_grad=True)
+                image = rast_exact(means3D=params["means3D"], means2D=m2, shs=params["shs"], colors_precomp=None,
+                                   opacities=params["opacities"], scales=params["scales"],
+                                   rotations=params["rotations"], cov3D_precomp=None)[0]
+                image.backward(G)
+            for _ in range(3):
+                exact_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                exact_step()
+            torch.cuda.synchronize()
+            ms_exact = (time.perf_counter() - t1) / 10 * 1e3
+            out["exact_mode"] = {"t_eps": 0.0, "ms_per_step": round(ms_exact, 4),
+                                 "value": round(W * H / (ms_exact * 1e-3) / 1e6, 2), "unit": "Mpix/s",
+                                 "note": "no early termination; 10 steps, wall time"}
         if world == 1 and not forward_only:
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
                                 "adam_densify_step": bench_adam(impl, params, radii, dev),

@@ -271,17 +271,22 @@ def main():
                     "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4),
-                    "limiter": ("VALU issue (SQ_ACTIVE_INST_VALU x4 / SIMD cycles = 87 % in render_bwd, ~100 % in render_fwd, "
-                                "profiles/r1d_pmc_sq_counters.txt); HBM accounting kept as the task prescribes")
+                    "limiter": ("VALU issue: 22 of the backward loop's 59 vector instructions are DPP adds, which issue "
+                                "at half rate (4.15 cycles measured, profiles/r1f_valu_issue_rates.txt); SQ_ACTIVE_INST_VALU "
+                                "x4 / SIMD cycles = 87 % in render_bwd (profiles/r1d_pmc_sq_counters.txt); HBM accounting "
+                                "kept as the task prescribes")
                     if dominant.startswith("render") else "HBM / latency (see DESIGN.md section 4)"}
         # secondary bound: VALU issue rate of the render kernels, from the SQ counters under profiles/
         try:
             vt = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
             if dominant in vt["kernels"] and args.config == "config3_garden_3M_sh3_1297x840" and args.t_eps is None:
                 rate = vt["kernels"][dominant]["valu_wave_insts"] / (stage_ms[dominant] * 1e-3)
+                peak = vt["kernels"][dominant].get("peak_wave_insts_per_s", vt["peak_wave_insts_per_s"])
                 roofline["valu"] = {"achieved_G_wave_insts_per_s": round(rate / 1e9, 1),
-                                    "peak_G_wave_insts_per_s": round(vt["peak_wave_insts_per_s"] / 1e9, 1),
-                                    "frac": round(rate / vt["peak_wave_insts_per_s"], 4), "source": vt["source"]}
+                                    "peak_G_wave_insts_per_s": round(peak / 1e9, 1),
+                                    "frac": round(rate / peak, 4), "source": vt["source"],
+                                    "peak_note": "issue peak for this kernel's instruction mix, from measured "
+                                                 "per-instruction issue costs (profiles/valu_insts.json)"}
         except (OSError, KeyError, ValueError):
             pass
         out = {

@@ -54,7 +54,10 @@ struct Rec { f4 q0, q1, q2; };
 constexpr float GS_LOG2E = 1.4426950408889634f;
 constexpr int GS_ROWS = 4;                 // 16-lane rows per wave, one 4x4 pixel block each
 constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
-constexpr int GS_BWD_BATCH = 32;           // pairs per backward batch: 16 blocks x 32 slots x 40 B = 20 KB of LDS
+#ifndef GS_BWD_BATCH_DEF
+#define GS_BWD_BATCH_DEF 32
+#endif
+constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch: 16 blocks x 32 slots x 40 B = 20 KB of LDS
 
 // LDS form of a splat record (written by stage_and_cull):
 //   q0 = (mean_x, mean_y, A', B')   q1 = (C', opacity, depth, x_min | y_min << 16)
@@ -136,7 +139,7 @@ template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
                                               uint32_t* wl, uint16_t* posmap, f4* conic = nullptr) {
-    static_assert(BATCH % 32 == 0 && BATCH >= 32 && BATCH <= GS_BLOCK, "one staging lane per pair");
+    static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
     if (tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];

@@ -47,6 +47,12 @@ __global__ void __launch_bounds__(256) pkfma_kernel(float* out, int iters, float
         out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;                      \
     }
 KERNEL1(dpp_kernel, "v_add_f32_dpp %0, %0, %1 row_ror:4 row_mask:0xf bank_mask:0xf")
+KERNEL1(dpp_quad_kernel, "v_add_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL1(dpp_shr_kernel, "v_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+KERNEL1(dpp_mirror_kernel, "v_add_f32_dpp %0, %0, %1 row_half_mirror row_mask:0xf bank_mask:0xf")
+KERNEL1(dpp_bank_kernel, "v_add_f32_dpp %0, %0, %1 row_ror:8 row_mask:0xf bank_mask:0x3")
+KERNEL1(mov_dpp_kernel, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL1(add_kernel, "v_add_f32 %0, %0, %1")
 KERNEL1(exp_kernel, "v_exp_f32 %0, %0")
 KERNEL1(rcp_kernel, "v_rcp_f32 %0, %0")
 KERNEL1(mul_kernel, "v_mul_f32 %0, %0, %1")
@@ -66,10 +72,13 @@ int main() {
     const int iters = 5000;
     struct { const char* name; void (*k)(float*, int, float, float); int flops; } K[] = {
         {"v_fma_f32      ", fma_kernel, 2}, {"v_pk_fma_f32   ", pkfma_kernel, 4}, {"v_mul_f32      ", mul_kernel, 1},
-        {"v_add_f32_dpp  ", dpp_kernel, 1}, {"v_exp_f32      ", exp_kernel, 1},   {"v_rcp_f32      ", rcp_kernel, 1},
+        {"v_add_f32_dpp ror4", dpp_kernel, 1}, {"v_add_f32_dpp quad_perm", dpp_quad_kernel, 1},
+        {"v_add_f32_dpp row_shr:1", dpp_shr_kernel, 1}, {"v_add_f32_dpp half_mirror", dpp_mirror_kernel, 1},
+        {"v_add_f32_dpp ror8 bank3", dpp_bank_kernel, 1}, {"v_mov_b32_dpp quad_perm", mov_dpp_kernel, 1},
+        {"v_add_f32      ", add_kernel, 1}, {"v_exp_f32      ", exp_kernel, 1},   {"v_rcp_f32      ", rcp_kernel, 1},
         {"v_pk_max_u16   ", pkmax_kernel, 1}, {"v_cndmask_b32  ", cndmask_kernel, 1}};
     for (auto& kk : K)
-        for (int wg_per_cu : {1, 2, 6, 8}) {        // 256-thread workgroups = 1 wave per SIMD each
+        for (int wg_per_cu : {1, 6}) {        // 256-thread workgroups = 1 wave per SIMD each
             const int grid = cus * wg_per_cu;
             kk.k<<<grid, 256>>>(out, 100, 1.0001f, 0.5f);
             CHECK(hipDeviceSynchronize());

@@ -59,6 +59,67 @@ KERNEL1(mul_kernel, "v_mul_f32 %0, %0, %1")
 KERNEL1(pkmax_kernel, "v_pk_max_u16 %0, %0, %1")
 KERNEL1(cndmask_kernel, "v_cndmask_b32 %0, %0, %1, vcc")
 
+// v_cndmask with an SGPR-pair mask (e64) and v_cmp writing VCC: the selects and compares of the render loops
+__global__ void __launch_bounds__(256) cndmask_sgpr_kernel(float* out, int iters, float a, float b) {
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    const unsigned long long m = __ballot((threadIdx.x & 1) == (b > 0.f));
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#define CM(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "s"(m))
+            CM(x0); CM(x1); CM(x2); CM(x3); CM(x4); CM(x5); CM(x6); CM(x7);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+__global__ void __launch_bounds__(256) cmp_kernel(float* out, int iters, float a, float b) {
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#define CP(x) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(x), "v"(a) : "vcc")
+            CP(x0); CP(x1); CP(x2); CP(x3); CP(x4); CP(x5); CP(x6); CP(x7);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+__global__ void __launch_bounds__(256) cndmask_vcc_kernel(float* out, int iters, float a, float b) {
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; ++i) {
+        asm volatile("s_mov_b64 vcc, 0x55555555" : : : "vcc");
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#define CV(x) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : )
+            CV(x0); CV(x1); CV(x2); CV(x3); CV(x4); CV(x5); CV(x6); CV(x7);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
+// one v_cndmask_b32_e32 (VCC mask) among seven v_mul_f32: its cost inside a mixed stream
+__global__ void __launch_bounds__(256) mixed_cndmask_kernel(float* out, int iters, float a, float b) {
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; ++i) {
+        asm volatile("s_mov_b64 vcc, 0x55555555" : : : "vcc");
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#define ML(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a))
+            ML(x0); ML(x1); ML(x2); CV(x3); ML(x4); ML(x5); ML(x6); ML(x7);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+// the same with the e64 form (mask in an SGPR pair)
+__global__ void __launch_bounds__(256) mixed_cndmask64_kernel(float* out, int iters, float a, float b) {
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    const unsigned long long m = __ballot((threadIdx.x & 1) == (b > 0.f));
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { ML(x0); ML(x1); ML(x2); CM(x3); ML(x4); ML(x5); ML(x6); ML(x7); }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
 int main() {
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
@@ -76,7 +137,10 @@ int main() {
         {"v_add_f32_dpp row_shr:1", dpp_shr_kernel, 1}, {"v_add_f32_dpp half_mirror", dpp_mirror_kernel, 1},
         {"v_add_f32_dpp ror8 bank3", dpp_bank_kernel, 1}, {"v_mov_b32_dpp quad_perm", mov_dpp_kernel, 1},
         {"v_add_f32      ", add_kernel, 1}, {"v_exp_f32      ", exp_kernel, 1},   {"v_rcp_f32      ", rcp_kernel, 1},
-        {"v_pk_max_u16   ", pkmax_kernel, 1}, {"v_cndmask_b32  ", cndmask_kernel, 1}};
+        {"v_pk_max_u16   ", pkmax_kernel, 1}, {"v_cndmask_b32 vcc (old)", cndmask_kernel, 1}, {"v_cndmask_b32_e32 vcc set", cndmask_vcc_kernel, 1},
+        {"v_cndmask_b32_e64 sgpr", cndmask_sgpr_kernel, 1}, {"v_cmp_gt_f32 vcc", cmp_kernel, 1},
+        {"7 v_mul + 1 v_cndmask_e32 vcc (per instruction)", mixed_cndmask_kernel, 1},
+        {"7 v_mul + 1 v_cndmask_e64 sgpr (per instruction)", mixed_cndmask64_kernel, 1}};
     for (auto& kk : K)
         for (int wg_per_cu : {1, 6}) {        // 256-thread workgroups = 1 wave per SIMD each
             const int grid = cus * wg_per_cu;

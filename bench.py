@@ -63,8 +63,8 @@ def bytes_depth_sort(N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="config3_garden_3M_sh3_1297x840", choices=list(CONFIGS))
     ap.add_argument("--t-eps", type=float, default=None, help="per-pixel stop threshold (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -81,10 +81,12 @@ def main():
                     help="take the N > 1 code path (process group, collectives) even with one rank")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.watchdog == 0 and world > 1:
+        args.watchdog = 900.0      # a collective that never returns ends with every thread's stack on stderr
     if args.watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:

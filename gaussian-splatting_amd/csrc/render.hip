@@ -60,16 +60,19 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch: 16 blocks x 32 slots x 40 B = 20 KB of LDS
 
 // LDS form of a splat record (written by stage_and_cull):
-//   q0 = (mean_x, mean_y, A', B')   q1 = (C', opacity, depth, x_min | y_min << 16)
-//   q2 = (red, green, blue, (x_max - 1) | (y_max - 1) << 16)
-// with A' = -0.5 log2e conic_a, B' = -log2e conic_b, C' = -0.5 log2e conic_d.
+//   q0 = (mean_x, mean_y, A', B')   q1 = (C', opacity, x_min | y_min << 16, (x_max - 1) | (y_max - 1) << 16)
+//   q2 = (red, green, blue, depth)
+// with A' = -0.5 log2e conic_a, B' = -log2e conic_b, C' = -0.5 log2e conic_d.  The box sits in one
+// 16-byte word (a visit is tested with q1 alone) and (red, green), (blue, depth) are aligned register
+// pairs for the forward's two v_pk_fma_f32.
 __device__ __forceinline__ void to_lds_form(f4& p0, f4& p1, f4& p2) {
     const uint32_t rx = __float_as_uint(p1.w), ry = __float_as_uint(p2.w);
     p0.z *= -0.5f * GS_LOG2E;
     p0.w *= -GS_LOG2E;
     p1.x *= -0.5f * GS_LOG2E;
-    p1.w = __uint_as_float((rx & 0xFFFFu) | (ry << 16));
-    p2.w = __uint_as_float(((rx >> 16) - 1u) | (((ry >> 16) - 1u) << 16));
+    p2.w = p1.z;                                                         // depth
+    p1.z = __uint_as_float((rx & 0xFFFFu) | (ry << 16));
+    p1.w = __uint_as_float(((rx >> 16) - 1u) | (((ry >> 16) - 1u) << 16));
 }
 
 // per-lane record read: `off` (bytes) is the same for the 16 lanes of a row -> three ds_read_b128
@@ -162,7 +165,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         const int j = r * 64 + lane;
         bool hx0 = false, hx1 = false, hy0 = false, hy1 = false;
         if (j < n) {
-            const uint32_t lo = squ[12 * j + 7], hi = squ[12 * j + 11];
+            const uint32_t lo = squ[12 * j + 6], hi = squ[12 * j + 7];
             const int xmin = lo & 0xFFFF, ymin = lo >> 16, xlast = hi & 0xFFFF, ylast = hi >> 16;
             hx0 = xmin < c.sx0 + GS_QUAD && xlast >= c.sx0;
             hx1 = xmin < c.sx0 + 2 * GS_QUAD && xlast >= c.sx0 + GS_QUAD;
@@ -185,15 +188,15 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         for (int p = cnt[q] + lane; p < nmax; p += 64) wl[q * (BATCH + 1) + p] = 48u * (uint32_t)BATCH;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    return nmax;
+    return __builtin_amdgcn_readfirstlane(nmax);      // wave-uniform: keep the visit loop's bound in an SGPR
 }
 
 __device__ __forceinline__ void write_pad_record(f4* sq, int BATCH) {
     if (threadIdx.x == 0) {
         const f4 z = {0.f, 0.f, 0.f, 0.f};
         sq[3 * BATCH] = z;
-        sq[3 * BATCH + 1] = f4{0.f, 0.f, 0.f, __uint_as_float(PAD_LO)};
-        sq[3 * BATCH + 2] = f4{0.f, 0.f, 0.f, __uint_as_float(PAD_HI)};
+        sq[3 * BATCH + 1] = f4{0.f, 0.f, __uint_as_float(PAD_LO), __uint_as_float(PAD_HI)};
+        sq[3 * BATCH + 2] = z;
     }
 }
 
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
             const Rec rec = load_rec(sq, off_next);
             off_next = mylist[kk + 1];       // entry nmax is never used (lists have BATCH + 1 entries)
-            const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
+            const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
             const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
             const float power2 = gauss_power2(rec, dx, dy);
             const float w = __builtin_amdgcn_exp2f(power2) * rec.q1.y;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
             Cr += alpha * rec.q2.x;
             Cg += alpha * rec.q2.y;
             Cb += alpha * rec.q2.z;
-            Z += alpha * rec.q1.z;
+            Z += alpha * rec.q2.w;
             A += alpha;
             T = 1.0f - A;
             P = T < t_eps ? P_STOPPED : P;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
             const Rec rec = load_rec(sq, off_next);
             off_next = mylist[kk + 1];
-            const bool act = in_box(P, __float_as_uint(rec.q1.w), __float_as_uint(rec.q2.w));
+            const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
             if (!__any(act)) continue;
             visited |= 1ull << kk;
             const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const float w = G * rec.q1.y;
             const float alpha = w * T;
             const float u = __builtin_fmaf(rec.q2.x, g_rg.x, __builtin_fmaf(rec.q2.y, g_rg.y,
-                            __builtin_fmaf(rec.q2.z, g_bz.x, __builtin_fmaf(rec.q1.z, g_bz.y, ga))));
+                            __builtin_fmaf(rec.q2.z, g_bz.x, __builtin_fmaf(rec.q2.w, g_bz.y, ga))));
             rem = __builtin_fmaf(-u, alpha, rem);      // total - sum_{j<=i} u_j alpha_j
             const float inv = __builtin_amdgcn_rcpf(fmaxf(1.0f - w, 1e-6f));
             const float dLdw = T * u - rem * inv;

@@ -54,6 +54,9 @@ struct Rec { f4 q0, q1, q2; };
 constexpr float GS_LOG2E = 1.4426950408889634f;
 constexpr int GS_ROWS = 4;                 // 16-lane rows per wave, one 4x4 pixel block each
 constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
+#ifndef GS_FWD_BATCH_DEF
+#define GS_FWD_BATCH_DEF 128     // pairs per forward batch (64 and 256 measured: see DESIGN.md)
+#endif
 #ifndef GS_BWD_BATCH_DEF
 #define GS_BWD_BATCH_DEF 32
 #endif
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, float* __restrict__ out_img,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, float* __restrict__ aux_rgb, float t_eps,
     f4* __restrict__ zero_buf, size_t zero_n) {
-    constexpr int BATCH = 128;
+    constexpr int BATCH = GS_FWD_BATCH_DEF;
     constexpr int NW = GS_BLOCK / 64;
     if (zero_buf) {
         // This kernel is VALU-bound and leaves HBM nearly idle: clearing the backward's gradient-row

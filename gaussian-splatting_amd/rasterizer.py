@@ -19,6 +19,7 @@ runs in libgsplat_hip.so (hand-written HIP for gfx950).  No CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -42,7 +43,20 @@ def grad_row_floats() -> int:
 # it (the reference's "no early termination"); what a pixel drops at the default is at most
 # 1e-5 * max|colour| (1e-5 * max depth for the depth map), a tenth of the stated 1e-4 image / 1e-3
 # depth tolerance; gradients lose terms of the same relative size.
-DEFAULT_T_EPS = 1e-5
+# GSPLAT_T_EPS in the environment (read once, at import) replaces the default for callers that cannot pass t_eps --
+# the reference's adapter constructs GaussianRasterizer(raster_settings=...) and nothing else: GSPLAT_T_EPS=0 gives
+# it the reference's exact compositing.
+def _default_t_eps() -> float:
+    v = os.environ.get("GSPLAT_T_EPS")
+    if v is None or v.strip() == "":
+        return 1e-5
+    t = float(v)
+    if not (0.0 <= t < 1.0):
+        raise ValueError(f"GSPLAT_T_EPS={v!r}: expected a transmittance threshold in [0, 1)")
+    return t
+
+
+DEFAULT_T_EPS = _default_t_eps()
 
 
 class GaussianRasterizationSettings:

@@ -77,3 +77,23 @@ def test_byte_model_matches_survey():
     b = bench.bytes_v1(3_000_000, 2_539_666, 7_535_647, 1297 * 840, 16, 82 * 53, 6)
     assert abs(sum(b.values()) / 1e9 - 4.99) < 0.02          # ~4.99 GB / frame
     assert round(b["radix_sort"] / 1e6) == 1145 and round(b["render_bwd"] / 1e6) == 788
+
+
+def test_default_t_eps_from_environment():
+    """GSPLAT_T_EPS replaces the default stop threshold at import (the reference's adapter cannot pass t_eps)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib; r = importlib.import_module('gaussian-splatting_amd.rasterizer'); "
+            "import inspect; print(r.DEFAULT_T_EPS, inspect.signature(r.GaussianRasterizer.__init__).parameters['t_eps'].default)")
+    for env_val, want in (("0", "0.0 0.0"), ("1e-7", "1e-07 1e-07"), (None, "1e-05 1e-05")):
+        env = dict(os.environ)
+        env.pop("GSPLAT_T_EPS", None)
+        if env_val is not None:
+            env["GSPLAT_T_EPS"] = env_val
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want
+    env = dict(os.environ, GSPLAT_T_EPS="2")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "GSPLAT_T_EPS" in out.stderr

@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--config", default="config3_garden_3M_sh3_1297x840", choices=list(CONFIGS))
     ap.add_argument("--t-eps", type=float, default=None, help="per-pixel stop threshold (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-mode", action="store_true",
+                    help="skip the extra t_eps = 0 timing (profiling runs: keeps one kind of render launch in the trace)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--parallel", default="exchange", choices=["exchange", "allreduce"],
                     help="N > 1: 'exchange' = Gaussians sharded, splat records / gradient rows exchanged "
@@ -316,7 +318,7 @@ def main():
                     "forward_out": (world - 1) * n_loc * 60, "backward_in": (world - 1) * n_loc * 4 * impl.rasterizer.grad_row_floats(),
                     "note": "60 B (record 48 + depth key 4 + box 8) per local Gaussian and remote view out, "
                             "48 B gradient row per local Gaussian and remote view back"}
-        if world == 1 and not forward_only and t_eps > 0:
+        if world == 1 and not forward_only and t_eps > 0 and not args.no_exact_mode:
             # the same frame without early termination (t_eps = 0: the reference's exact semantics, the mode the
             # parity tests pin); reported beside the headline, which runs at the library's default t_eps
             rast_exact = dgr.GaussianRasterizer(settings, t_eps=0.0)

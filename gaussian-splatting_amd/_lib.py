@@ -41,6 +41,8 @@ PROTOTYPES = {
     "gs_duplicate_with_keys": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "gs_sort_workspace_bytes": (_sz, [_ll]),
     "gs_sort_pairs": (_i, [_ll, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "gs_sort_pairs_static_max": (_ll, []),
+    "gs_sort_pairs_static": (_i, [_ll, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gs_identify_tile_ranges": (_i, [_ll, _vp, _i, _vp, _vp, _vp]),
     "gs_render_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _sz, _vp]),
     "gs_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -19,6 +19,7 @@
 //      run is written contiguously.
 // HBM-bound: per pass 4 B read (histogram) + 8 B read + 8 B written per pair.
 #include "gsplat_common.h"
+#include <mutex>
 
 namespace {
 
@@ -225,9 +226,9 @@ extern "C" size_t gs_sort_workspace_bytes(long long D) {
 // the input; *result_in_b tells which buffer pair holds the output (b after an odd number of passes).
 // count_dev (device, may be NULL): sort min(*count_dev, D) pairs -- D is then only the capacity that
 // sizes grids and workspace, so the caller needs no host read-back of the pair count.
-extern "C" int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
-                             uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* workspace,
-                             size_t workspace_bytes, int* result_in_b, void* stream_) {
+static int sort_pairs_impl(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
+                           uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* workspace,
+                           size_t workspace_bytes, int* result_in_b, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GS_REQUIRE(D >= 0 && D < (1ll << 32) && result_in_b, "bad arguments");
     GS_REQUIRE(bit_begin >= 0 && bit_begin <= bit_end && bit_end <= 32, "bad bit range [%d,%d)", bit_begin, bit_end);
@@ -260,4 +261,68 @@ extern "C" int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_beg
     }
     *result_in_b = pass & 1;
     return GS_OK;
+}
+
+extern "C" int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
+                             uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* workspace,
+                             size_t workspace_bytes, int* result_in_b, void* stream_) {
+    return sort_pairs_impl(D, count_dev, bit_begin, bit_end, keys_a, vals_a, keys_b, vals_b, workspace, workspace_bytes,
+                           result_in_b, stream_);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gs_sort_pairs_static: the same sort for callers that cannot allocate (HIP graph capture, serving
+// loops, harnesses that forbid hipMalloc).  The histogram tables (blk + grp, what gs_sort_pairs takes
+// as `workspace`) live in a file-scope device array instead; every GPU the library runs on holds its
+// own copy of it until the process ends.  `scratch` below is only the HOST-side handle of that array:
+// the per-device address comes from hipGetSymbolAddress, once per device, and only that pointer is
+// ever handed to kernels and memsets.
+// ---------------------------------------------------------------------------------------------
+#define GS_SORT_STATIC_MAX_PAIRS (1ll << 24)
+namespace {
+constexpr size_t static_blk_bytes = (size_t)(GS_SORT_STATIC_MAX_PAIRS / RS_TILE) * RS_RADIX * sizeof(uint32_t);
+constexpr size_t static_grp_bytes = (size_t)(GS_SORT_STATIC_MAX_PAIRS / RS_TILE / RS_GROUP) * RS_RADIX * sizeof(uint32_t);
+constexpr size_t SCRATCH_BYTES = static_blk_bytes + RS_MAX_PASSES * static_grp_bytes + 256;   // 4.5 MiB + 256
+constexpr int MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+static void* scratch_ptr[MAX_DEVICES];          // per device: address of that device's copy of `scratch`
+static std::mutex scratch_mutex;
+
+static int scratch_for_current_device(void** out) {
+    int dev = -1;
+    GS_CHECK_HIP(hipGetDevice(&dev));
+    GS_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index %d outside 0..%d", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr[dev]) {
+        void* p = nullptr;
+        GS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        GS_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null scratch address");
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return GS_OK;
+}
+
+extern "C" long long gs_sort_pairs_static_max(void) { return GS_SORT_STATIC_MAX_PAIRS; }
+
+extern "C" int gs_sort_pairs_static(long long D, const uint32_t* count_dev, int bit_begin, int bit_end,
+                                    uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                                    int* result_in_b, void* stream_) {
+    if (D > GS_SORT_STATIC_MAX_PAIRS) {
+        gs_set_error("gs_sort_pairs_static: %lld pairs exceed the static scratch (at most %lld); use gs_sort_pairs with a "
+                     "caller workspace", D, (long long)GS_SORT_STATIC_MAX_PAIRS);
+        return GS_ERR_SIZE;
+    }
+    GS_REQUIRE(D >= 0 && result_in_b, "bad arguments");
+    if (gs_sort_workspace_bytes(D) > SCRATCH_BYTES) {      // cannot happen for D <= the maximum; guards a retuned tile size
+        gs_set_error("gs_sort_pairs_static: workspace for %lld pairs larger than the static scratch", D);
+        return GS_ERR_SIZE;
+    }
+    void* ws = nullptr;
+    const int rc = scratch_for_current_device(&ws);
+    if (rc != GS_OK) return rc;
+    // the tables are rewritten (blk) or cleared (grp) by every call: nothing of the previous call is read
+    return sort_pairs_impl(D, count_dev, bit_begin, bit_end, keys_a, vals_a, keys_b, vals_b, ws, SCRATCH_BYTES,
+                           result_in_b, stream_);
 }

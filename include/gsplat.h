@@ -20,7 +20,8 @@
  *     alpha clamp, background added un-attenuated) are those of the reference's built-in
  *     PyTorch rasterizer, gaussian_renderer/__init__.py:64-442 (the parity oracle).
  *
- * Re-entrancy: no global mutable state except the thread-local error string.
+ * Re-entrancy: no global mutable state except the thread-local error string and, for
+ * gs_sort_pairs_static only, the per-GPU static scratch array documented there.
  */
 #ifndef GSPLAT_H
 #define GSPLAT_H
@@ -99,6 +100,20 @@ size_t gs_sort_workspace_bytes(long long D);
 int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
                   uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* workspace, size_t workspace_bytes,
                   int* result_in_b, void* stream);
+/*
+ * gs_sort_pairs for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same sort, same
+ * arguments minus the workspace: the histogram tables live in a file-scope device array of the library
+ * (4.5 MiB per GPU the library runs on, held until the process ends), so the call allocates nothing --
+ * no hipMalloc / hipFree, no allocating library routine.  At most gs_sort_pairs_static_max() = 2^24
+ * pairs (capacity D); more returns GS_ERR_SIZE and gs_last_error() says so.  The device that owns
+ * `stream` must be the current device.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (two streams, two threads) race -- serialise them or use gs_sort_pairs with workspaces of
+ * their own.  Every call rewrites or clears what it reads, so back-to-back calls need no clean-up.
+ */
+long long gs_sort_pairs_static_max(void);
+int gs_sort_pairs_static(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
+                         uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int* result_in_b, void* stream);
 /* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty); count_dev as
  * in gs_sort_pairs. */
 int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, int num_tiles, const uint32_t* keys,

@@ -317,7 +317,7 @@ def main():
                 out["exchange_bytes_per_rank_and_step"] = {
                     "forward_out": (world - 1) * n_loc * 60, "backward_in": (world - 1) * n_loc * 4 * impl.rasterizer.grad_row_floats(),
                     "note": "60 B (record 48 + depth key 4 + box 8) per local Gaussian and remote view out, "
-                            "48 B gradient row per local Gaussian and remote view back"}
+                            "64 B gradient row per local Gaussian and remote view back"}
         if world == 1 and not forward_only and t_eps > 0 and not args.no_exact_mode:
             # the same frame without early termination (t_eps = 0: the reference's exact semantics, the mode the
             # parity tests pin); reported beside the headline, which runs at the library's default t_eps

@@ -16,10 +16,13 @@
 // conic = inverse of the 2x2 screen covariance, [[a,b],[b,d]]; rect is the
 // reference's hard integer 3-sigma box (:393-399), half-open, clipped to the image.
 //
-// The backward per-Gaussian gradient rows are GS_GRAD_ROW = 12 floats (48 B: three float4 reads in
-// preprocess_bwd; 16 floats measured 1.4 % slower per frame and cost a quarter more on the wire):
-//   [0] d mean_x  [1] d mean_y  [2] d conic_a  [3] d conic_b (each off-diagonal entry)
-//   [4] d conic_d [5] d opacity [6..8] d rgb   [9] d depth   [10,11] unused
+// The backward per-Gaussian gradient rows are GS_GRAD_ROW = 16 floats = 64 bytes, one aligned 64-byte
+// segment per Gaussian.  The five geometric sums are accumulated as DOUBLES (bytes 0..39):
+//   d[0] d mean_x  d[1] d mean_y  d[2] d conic_a  d[3] d conic_b (each off-diagonal entry)  d[4] d conic_d
+// -- their chain rule through the 2x2 inverse cancels by orders of magnitude for large, nearly singular
+// splats, so the order in which the tiles' float atomics arrive used to move d means3D by ~1e-3 of its
+// value from run to run; fp64 atomics make the sums order-independent (bit-reproducible gradients) --
+// and the rest as floats (bytes 40..59): f[10] d opacity  f[11..13] d rgb  f[14] d depth  f[15] unused.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,7 +31,7 @@
 #define GS_SUB 8            // one wave64 owns an 8x8 sub-tile
 #define GS_BLOCK 256        // threads per tile workgroup = 4 waves
 #ifndef GS_GRAD_ROW
-#define GS_GRAD_ROW 12      // floats per gradient row (10 used; a multiple of 4: the rows are read as float4s)
+#define GS_GRAD_ROW 16      // floats per gradient row (see above; the rows are read as float4s)
 #endif
 
 #define GS_OK 0

@@ -345,11 +345,17 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (drawn) {
         Geom g;
         if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
-        const float4 r0 = PART != 2 ? grad_rows[(GS_GRAD_ROW / 4) * (size_t)i] : make_float4(0.f, 0.f, 0.f, 0.f),
-                     r1 = grad_rows[(GS_GRAD_ROW / 4) * (size_t)i + 1], r2 = grad_rows[(GS_GRAD_ROW / 4) * (size_t)i + 2];
-        const float d_mx = r0.x, d_my = r0.y, d_a = r0.z, d_b = r0.w;
-        const float d_d = r1.x, d_op = r1.y, d_r = r1.z, d_g = r1.w;
-        const float d_bl = r2.x, d_z = r2.y;
+        // row = 5 doubles (mean x, y, conic a, b, d) + floats 10..14 (opacity, r, g, b, depth): gsplat_common.h
+        static_assert(GS_GRAD_ROW == 16, "row layout");
+        const float4* row = grad_rows + (GS_GRAD_ROW / 4) * (size_t)i;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r0 = PART != 2 ? row[0] : z4, r1 = PART != 2 ? row[1] : z4, r2 = row[2], r3 = row[3];
+        const auto dbl = [](float lo, float hi) {
+            return (float)__hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo));
+        };
+        const float d_mx = dbl(r0.x, r0.y), d_my = dbl(r0.z, r0.w), d_a = dbl(r1.x, r1.y), d_b = dbl(r1.z, r1.w);
+        const float d_d = dbl(r2.x, r2.y), d_op = r2.z, d_r = r2.w, d_g = r3.x;
+        const float d_bl = r3.y, d_z = r3.z;
         gop = d_op;
         gm2[0] = d_mx;
         gm2[1] = d_my;

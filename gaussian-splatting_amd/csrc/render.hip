@@ -33,15 +33,16 @@
 // Backward gradient accumulation: per Gaussian 10 partial sums (the mean/conic ones as raw
 // moments sum q dx, q dy, q dx^2, q dx dy, q dy^2 with q = dL/dpower; the per-Gaussian factors are
 // applied at flush time) are reduced over the 16 lanes of the row by a select-free DPP
-// reduce-scatter (22 adds, registers only); 11 lanes of every row then add their totals into the
-// pair's 48-byte LDS accumulator with ONE ds_add_f32 per visit (rows that visit the same pair in
-// the same instruction serialise on the address: a few cycles); after the batch the sums are
-// flushed once per (tile, Gaussian) as one 40-byte row-shaped float atomic into that Gaussian's
-// 48-byte gradient row.
+// reduce-scatter (22 adds, registers only); ten lanes of every row then store one dword each into
+// the 40-byte LDS slot of (4x4 block, list position) -- plain stores; after the batch the 16 lanes
+// of a DPP row take one pair each, lane b reads block b's slot, the same reduce-scatter adds the
+// 16 blocks up, and one row-shaped atomic per (tile, Gaussian) goes into that Gaussian's 64-byte
+// gradient row (the five geometric sums as fp64 atomics: gsplat_common.h).
 //
 // Bound: VALU issue (~21 instructions per visit forward, ~60 backward); HBM traffic is the record
 // gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
 #include "gsplat_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -59,6 +60,12 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #endif
 #ifndef GS_BWD_BATCH_DEF
 #define GS_BWD_BATCH_DEF 32
+#endif
+#ifndef GS_BWD4_BATCH
+#define GS_BWD4_BATCH 32     // pairs per batch of the one-wave-per-tile backward
+#endif
+#ifndef GS_BWD4_CAP
+#define GS_BWD4_CAP 256      // (pair, block) slots per batch
 #endif
 constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch: 16 blocks x 32 slots x 40 B = 20 KB of LDS
 
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
             Z += alpha * rec.q2.w;
             A += alpha;
             T = 1.0f - A;
-            P = T < t_eps ? P_STOPPED : P;
+            P = T <= t_eps ? P_STOPPED : P;   // t_eps = 0: stops at T == 0 exactly, where every later alpha is 0 anyway
         }
     }
     if (c.inside) {
@@ -279,8 +286,42 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
 //   t = 0: v[(b&1 ? 2 : 0) + 5 (b>>1)]   t = 1: v[(b&1 ? 3 : 1) + 5 (b>>1)]   t = 2: v[4 + 5 (b>>1)]
 // (tools/dpp_test/t3.hip is the standalone check).  s_nop: a DPP operand needs 2 wait states after
 // the VALU write of that register.
+template <bool HAS9 = true>
 __device__ __forceinline__ float row_reduce_scatter10(const float (&v)[10], int t) {
     float o0, o1, o2, o3, o4, p0, p1, p2;
+    if (!HAS9) {
+        // v[9] is not needed: one add fewer; the lanes that would end up with its total (banks 2,3, t = 2) hold
+        // leftovers and must not be stored
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %1, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %2, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %3, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %5, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %6, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %5, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %6, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %7, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x1\n\t"
+            "v_add_f32_dpp %7, %4, %4 row_shr:4 row_mask:0xf bank_mask:0x2\n\t"
+            "s_nop 0\n\t"
+            "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0x3\n\t"
+            "s_nop 1"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(p0), "=&v"(p1), "=&v"(p2)
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+              "v"(v[9]));
+        return t == 0 ? p0 : (t == 1 ? p1 : p2);
+    }
     asm volatile(
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
@@ -313,7 +354,14 @@ __device__ __forceinline__ float row_reduce_scatter10(const float (&v)[10], int 
     return t == 0 ? p0 : (t == 1 ? p1 : p2);
 }
 
-template <int BATCH>
+// gradient row (GS_GRAD_ROW = 16 floats = 64 bytes, see gsplat_common.h): sums 0..4 are doubles
+__device__ __forceinline__ void add_to_row(float* row, int idx, double v) {
+    if (idx < 5) atomicAdd(reinterpret_cast<double*>(row) + idx, v);
+    else atomicAdd(row + 5 + idx, (float)v);
+}
+
+// HAS_ZA: an upstream gradient of the depth or alpha output exists (otherwise u has three terms and the depth sum is skipped)
+template <int BATCH, bool HAS_ZA>
 __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
@@ -356,7 +404,8 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     int red_slot = -1;
     if (t == 0) red_slot = ((bank & 1) ? 2 : 0) + 5 * (bank >> 1);
     else if (t == 1) red_slot = ((bank & 1) ? 3 : 1) + 5 * (bank >> 1);
-    else if (t == 2 && !(bank & 1)) red_slot = 4 + 5 * (bank >> 1);
+    else if (t == 2 && !(bank & 1) && (HAS_ZA || bank == 0)) red_slot = 4 + 5 * (bank >> 1);
+    static_assert(BATCH <= 64 && BATCH % 16 == 0, "64-bit visited mask; the flush takes 16 pairs per round");
     // this lane's float inside slot 0 of its row's block
     float* my_slot = slots + (size_t)(wave * GS_ROWS + (lane >> 4)) * BATCH * SLOT + (red_slot < 0 ? 0 : red_slot);
     write_pad_record(sq, BATCH);
@@ -380,16 +429,27 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const float G = act ? __builtin_amdgcn_exp2f(power2) : 0.0f;  // inactive lanes: every sum gets 0
             const float w = G * rec.q1.y;
             const float alpha = w * T;
-            const float u = __builtin_fmaf(rec.q2.x, g_rg.x, __builtin_fmaf(rec.q2.y, g_rg.y,
-                            __builtin_fmaf(rec.q2.z, g_bz.x, __builtin_fmaf(rec.q2.w, g_bz.y, ga))));
+            const float u = HAS_ZA ? __builtin_fmaf(rec.q2.x, g_rg.x, __builtin_fmaf(rec.q2.y, g_rg.y,
+                                         __builtin_fmaf(rec.q2.z, g_bz.x, __builtin_fmaf(rec.q2.w, g_bz.y, ga))))
+                                   : __builtin_fmaf(rec.q2.x, g_rg.x, __builtin_fmaf(rec.q2.y, g_rg.y, rec.q2.z * g_bz.x));
+            A += alpha;
+            const float Tn = 1.0f - A;
+            const bool stop = Tn <= t_eps;
             rem = __builtin_fmaf(-u, alpha, rem);      // total - sum_{j<=i} u_j alpha_j
-            const float inv = __builtin_amdgcn_rcpf(fmaxf(1.0f - w, 1e-6f));
+            // Behind a pixel that stops here nothing is composited (every later alpha is 0, exactly so for
+            // t_eps = 0), so the tail term is 0 by definition -- not the rounding residue of total - prefix
+            // (~1e-7 |total|), which would otherwise leak into the sums of every hidden Gaussian.  A pixel that
+            // goes on has 1 - w > 0, so the reciprocal needs no clamp.
+            const float inv = stop ? 0.0f : __builtin_amdgcn_rcpf(1.0f - w);
             const float dLdw = T * u - rem * inv;
             const float q = w * dLdw;          // dL/dpower
             const f2 dxy = {dx, dy};
             const f2 qxy = q * dxy;            // v_pk_mul_f32
             const f2 qxd = qxy.x * dxy;
-            const f2 c_rg = alpha * g_rg, c_bz = alpha * g_bz;
+            const f2 c_rg = alpha * g_rg;
+            f2 c_bz;
+            if (HAS_ZA) c_bz = alpha * g_bz;
+            else c_bz = f2{alpha * g_bz.x, 0.0f};
             float v[10];
             v[0] = qxy.x;
             v[1] = qxy.y;
@@ -401,10 +461,9 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             v[7] = c_rg.y;
             v[8] = c_bz.x;
             v[9] = c_bz.y;
-            A += alpha;
-            T = 1.0f - A;
-            P = T < t_eps ? P_STOPPED : P;
-            const float red = row_reduce_scatter10(v, t);
+            T = Tn;
+            P = stop ? P_STOPPED : P;
+            const float red = row_reduce_scatter10<HAS_ZA>(v, t);
             if (red_slot >= 0) my_slot[kk * SLOT] = red;   // one ds_write_b32 per visit, 10 lanes per row
         }
         if (lane == 0) visited_all[wave] = visited;
@@ -430,7 +489,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             float v[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) v[k] = sl[k];
-            const float sum = row_reduce_scatter10(v, t);
+            const float sum = row_reduce_scatter10<HAS_ZA>(v, t);
             const float other = __shfl_xor(sum, 1);
             if (any && red_slot >= 0) {
                 float outv = sum;
@@ -440,9 +499,313 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                 } else if (red_slot < 5) {
                     outv = -0.5f * sum;
                 }
-                atomicAdd(grad_rows + (size_t)sid[j] * GS_GRAD_ROW + red_slot, outv);
+                add_to_row(grad_rows + (size_t)sid[j] * GS_GRAD_ROW, red_slot, outv);
             }
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Backward, second form: ONE wave64 per 16x16 tile, FOUR pixels per lane.
+//
+// Why: the first form (lane = pixel, 16 lanes per 4x4 block) spends 22 of its 59 instructions per visit
+// on the 16-lane reduce-scatter, and those DPP adds issue at half rate.  Here a 4x4 block is 4 lanes
+// (lane = one 4x1 pixel strip); the four lanes of a block sit in the four banks of a DPP row (lanes
+// q, q+4, q+8, q+12), so the whole cross-lane reduction is the two select-free halving steps (row_ror:8,
+// row_shl/shr:4 with bank masks): 16 DPP adds per 256 pixel-slots instead of 22 per 64.  The four
+// pixels of a lane are added up with plain full-rate VALU first, and share dy, C' dy and the record.
+// A wave now walks SIXTEEN hit lists (one per block) in lockstep.
+//
+// LDS per wave (= per workgroup): records, the 16 lists (entry = record offset | slot offset << 16),
+// and a COMPACT slot array: one 48-byte slot per (pair, block it overlaps), allocated by a prefix sum
+// over the batch -- ~6 slots per pair on the benchmark scene instead of 16 -- capped at CAP slots: a
+// batch is cut short when its pairs need more.  The flush adds a pair's slots (contiguous) in double
+// and issues one row-shaped atomic per (tile, Gaussian).  No __syncthreads anywhere.
+// ---------------------------------------------------------------------------------------------
+
+
+// First two steps of row_reduce_scatter10: halves 10 values over lane^8 and lane^4.  Lane with bank
+// b = (lane >> 2) & 3 ends with the totals over {lane, lane^4, lane^8, lane^12} of
+//   p0 = v[(b&1 ? 2 : 0) + 5 (b>>1)]   p1 = v[(b&1 ? 3 : 1) + 5 (b>>1)]   p2 = v[4 + 5 (b>>1)]
+__device__ __forceinline__ void bank_reduce_scatter10(const float (&v)[10], float& p0, float& p1, float& p2) {
+    float o0, o1, o2, o3, o4;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(p0), "=&v"(p1), "=&v"(p2)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+          "v"(v[9]));
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+#ifdef GS_BWD4_STATS
+__device__ unsigned long long g_bwd4_stats[8];   // batches, wave-visits, block-visits with a live lane, sum n_eff, sum nslots, flush iterations, live lane-pixels
+#define B4_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bwd4_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define B4_STAT(i, v) do { } while (0)
+#endif
+
+template <int BATCH, int CAP, bool HAS_ZA>
+__global__ __launch_bounds__(64) void render_bwd4_kernel(
+    int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
+    const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
+    const float* __restrict__ g_depth, const float* __restrict__ g_alpha, float* __restrict__ grad_rows,
+    float t_eps) {
+    static_assert(BATCH >= 16 && BATCH <= 64 && BATCH % 4 == 0, "one staging lane per pair");
+    static_assert(CAP >= 16 && 48 * (CAP + 1) < 65536 && 48 * (BATCH + 1) < 65536, "list entries are two 16-bit byte offsets");
+    constexpr int NBLK = 16;            // 4x4-pixel blocks per tile, one hit list each
+    constexpr int LSTR = BATCH + 1;     // list stride (odd: the 16 lists start in different banks; +1 for the prefetch)
+    constexpr int SLOTF = 12;           // floats per slot: 4 lanes x (p0, p1, p2)
+    constexpr uint32_t PAD_ENTRY = 48u * BATCH | (48u * CAP) << 16;   // pad record, dump slot
+    __shared__ f4 sq[3 * (BATCH + 1)];
+    __shared__ f4 conic[BATCH];
+    __shared__ uint32_t sid[BATCH];
+    __shared__ __align__(16) uint32_t lists[(NBLK * LSTR + 3) / 4 * 4];
+    __shared__ uint32_t hit_off[BATCH + 1];
+    __shared__ __align__(16) float slots[(CAP + 1) * SLOTF];
+    const int lane = threadIdx.x;
+    const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
+    const int tx0 = (tile % tiles_x) * GS_TILE, ty0 = (tile / tiles_x) * GS_TILE;
+    // lane -> block (brow, bcol) of the 4x4 grid of blocks, strip k of the block: pixels (x0 .. x0+3, y)
+    const int brow = lane >> 4, bcol = lane & 3, k = (lane >> 2) & 3;
+    const int y = ty0 + 4 * brow + k, x0 = tx0 + 4 * bcol;
+    const uint32_t* mylist = lists + (brow * 4 + bcol) * LSTR;
+    const uint2 range = ranges[tile];
+    const float fy = (float)y;
+    float fx[4], gr[4], gg[4], gb[4], gz[4], ga[4], A[4], T[4], rem[4];
+    uint32_t P[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        const bool inside = x < W && y < H;
+        fx[e] = (float)x;
+        gr[e] = gg[e] = gb[e] = gz[e] = ga[e] = 0.f;
+        A[e] = 0.f;
+        T[e] = 1.f;
+        rem[e] = 0.f;
+        P[e] = inside ? ((uint32_t)x | (uint32_t)y << 16) : P_STOPPED;
+        if (inside) {
+            const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
+            gr[e] = g_img[p];
+            gg[e] = g_img[HW + p];
+            gb[e] = g_img[2 * HW + p];
+            if (g_depth) gz[e] = g_depth[p];
+            if (g_alpha) ga[e] = g_alpha[p];
+            rem[e] = (gr[e] * aux_rgb[p] + gg[e] * aux_rgb[HW + p] + gb[e] * aux_rgb[2 * HW + p]) + gz[e] * out_depth[p] +
+                     ga[e] * out_alpha[p];
+        }
+    }
+    // which sum of the gradient row this lane owns in the flush (16 lanes per pair, lane c reads float c
+    // of the pair's slots: c = 3 * bank + i holds p_i of bank_reduce_scatter10); -1: nothing
+    //   c: 0 Sx  1 Sy  2 Syy  3 Sxx  4 Sxy  5 (dup)  6 opacity  7 red  8 depth  9 green  10 blue  11 (dup)
+    const int fc = lane & 15;
+    int oidx = -1;
+    {
+        constexpr int map[16] = {0, 1, 4, 2, 3, -1, 5, 6, 9, 7, 8, -1, -1, -1, -1, -1};
+        oidx = map[fc];
+    }
+    if (lane == 0) {
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        sq[3 * BATCH] = z;
+        sq[3 * BATCH + 1] = f4{0.f, 0.f, __uint_as_float(PAD_LO), __uint_as_float(PAD_HI)};
+        sq[3 * BATCH + 2] = z;
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t n_eff = 0;
+    for (uint32_t base = range.x; base < range.y; base += n_eff) {
+        const bool done = (P[0] & P[1] & P[2] & P[3]) == P_STOPPED;
+        if (__all(done)) break;
+        const int n = min((int)(range.y - base), BATCH);
+        // ---- stage the records, find the blocks every pair overlaps
+        uint32_t hm = 0;
+        if (lane < n) {
+            const uint32_t id = point_list[base + lane];
+            const f4* p = (const f4*)splat + 3 * (size_t)id;
+            f4 p0 = p[0], p1 = p[1], p2 = p[2];
+            conic[lane] = f4{p0.z, p0.w, p1.x, 0.f};
+            const uint32_t rx = __float_as_uint(p1.w), ry = __float_as_uint(p2.w);
+            to_lds_form(p0, p1, p2);
+            sq[3 * lane] = p0;
+            sq[3 * lane + 1] = p1;
+            sq[3 * lane + 2] = p2;
+            sid[lane] = id;
+            const int xa = max((int)(rx & 0xFFFF), tx0) - tx0, xb = min((int)(rx >> 16) - 1, tx0 + GS_TILE - 1) - tx0;
+            const int ya = max((int)(ry & 0xFFFF), ty0) - ty0, yb = min((int)(ry >> 16) - 1, ty0 + GS_TILE - 1) - ty0;
+            if (xa <= xb && ya <= yb) {
+                const uint32_t cm = (2u << (xb >> 2)) - (1u << (xa >> 2));
+                const uint32_t rm = (2u << (yb >> 2)) - (1u << (ya >> 2));
+                hm = cm * ((rm & 1u) | (rm & 2u) << 3 | (rm & 4u) << 6 | (rm & 8u) << 9);
+            }
+        }
+        // blocks whose 16 pixels have all stopped take no more pairs (their lanes: q, q+4, q+8, q+12 of a row)
+        {
+            const uint64_t dm = __ballot((P[0] & P[1] & P[2] & P[3]) == P_STOPPED);
+            const uint64_t all4 = dm & (dm >> 4) & (dm >> 8) & (dm >> 12);       // bit 16 r + q: block (r, q) is done
+            const uint32_t done = (uint32_t)(all4 & 0xFull) | (uint32_t)((all4 >> 16) & 0xFull) << 4 |
+                                  (uint32_t)((all4 >> 32) & 0xFull) << 8 | (uint32_t)((all4 >> 48) & 0xFull) << 12;
+            hm &= ~done;
+        }
+        const uint32_t cnt = __popc(hm);
+        const uint32_t incl = wave_incl_scan_u32(cnt, lane);
+        n_eff = __popcll(__ballot(lane < n && incl <= (uint32_t)CAP));     // >= 1: a pair has at most 16 slots
+        if (lane >= (int)n_eff) hm = 0;
+        const uint32_t excl = incl - cnt;
+        if (lane < (int)n_eff) hit_off[lane] = excl;
+        if (lane == (int)n_eff - 1) hit_off[n_eff] = incl;
+        const uint32_t nslots = __builtin_amdgcn_readlane(incl, n_eff - 1);   // may be 0: every block the batch touches is done
+        // ---- lists: everything is a pad entry first, then the hits in list order
+        {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 padv = {PAD_ENTRY, PAD_ENTRY, PAD_ENTRY, PAD_ENTRY};
+            u4* l4 = (u4*)lists;
+            for (int i = lane; i < (NBLK * LSTR + 3) / 4; i += 64) l4[i] = padv;
+            const f4 z = {0.f, 0.f, 0.f, 0.f};
+            f4* s4 = (f4*)slots;
+            for (int i = lane; i < (int)nslots * 3; i += 64) s4[i] = z;    // a block that stops early leaves zeros
+        }
+        int nmax = 0;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const bool hit = (hm >> b) & 1u;
+            const uint64_t m = __ballot(hit);
+            if (hit) {
+                const uint32_t slot = excl + __popc(hm & ((1u << b) - 1u));
+                lists[b * LSTR + __popcll(m & lt)] = 48u * (uint32_t)lane | (48u * slot) << 16;
+            }
+            nmax = max(nmax, (int)__popcll(m));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        B4_STAT(0, 1); B4_STAT(3, n_eff); B4_STAT(4, nslots);
+        // ---- visits
+        // list entry two visits ahead, record one visit ahead: the only LDS latency left in the loop is hidden
+        uint32_t e_cur = mylist[0], e_next = mylist[nmax > 1 ? 1 : 0];
+        Rec rec_next = load_rec(sq, e_cur & 0xFFFFu);
+        for (int kk = 0; kk < nmax; ++kk) {
+            if ((kk & 7) == 0 && __all((P[0] & P[1] & P[2] & P[3]) == P_STOPPED)) break;
+            const uint32_t entry = e_cur;
+            const Rec rec = rec_next;
+            e_cur = e_next;
+            rec_next = load_rec(sq, e_cur & 0xFFFFu);        // entries past the list are pad entries (lists are pre-filled)
+            e_next = mylist[kk + 2 <= BATCH ? kk + 2 : BATCH];
+            const uint32_t lo = __float_as_uint(rec.q1.z), hi = __float_as_uint(rec.q1.w);
+            const float dy = fy - rec.q0.y;
+            const float bdy = rec.q0.w, cdy = rec.q1.x * dy;
+            float q[4], pv[4], al[4], dx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool act = in_box(P[e], lo, hi);
+                dx[e] = fx[e] - rec.q0.x;
+                const float t = __builtin_fmaf(bdy, dy, rec.q0.z * dx[e]);          // same rounding as gauss_power2
+                const float power2 = __builtin_fmaf(cdy, dy, t * dx[e]);
+                const float G = act ? __builtin_amdgcn_exp2f(power2) : 0.0f;
+                const float w = G * rec.q1.y;
+                const float alpha = w * T[e];
+                const float u = HAS_ZA ? __builtin_fmaf(rec.q2.x, gr[e], __builtin_fmaf(rec.q2.y, gg[e],
+                                             __builtin_fmaf(rec.q2.z, gb[e], __builtin_fmaf(rec.q2.w, gz[e], ga[e]))))
+                                       : __builtin_fmaf(rec.q2.x, gr[e], __builtin_fmaf(rec.q2.y, gg[e], rec.q2.z * gb[e]));
+                A[e] += alpha;
+                const float Tn = 1.0f - A[e];
+                const bool stop = Tn <= t_eps;
+                rem[e] = __builtin_fmaf(-u, alpha, rem[e]);      // total - sum_{j<=i} u_j alpha_j
+                // Behind a pixel that stops here nothing is composited (every later alpha is 0, exactly so for
+                // t_eps = 0), so the tail term is 0 by definition -- not the rounding residue of total - prefix.
+                // A pixel that goes on has 1 - w > 0, so the reciprocal needs no clamp.
+                const float inv = stop ? 0.0f : __builtin_amdgcn_rcpf(1.0f - w);
+                const float dLdw = T[e] * u - rem[e] * inv;
+                pv[e] = G * dLdw;
+                q[e] = w * dLdw;
+                al[e] = alpha;
+                T[e] = Tn;
+                P[e] = stop ? P_STOPPED : P[e];
+            }
+#ifdef GS_BWD4_STATS
+            {
+                B4_STAT(1, 1);
+                const bool live = (entry & 0xFFFFu) != 48u * BATCH && (P[0] & P[1] & P[2] & P[3]) != P_STOPPED;
+                const unsigned long long lm = __ballot(live);
+                unsigned nb = 0;
+                for (int b = 0; b < 16; ++b) nb += ((lm >> ((b >> 2) * 16 + (b & 3))) & 0x1111ull) != 0;
+                B4_STAT(2, nb);
+                const unsigned long long a4 = __popcll(__ballot(al[0] != 0.f)) + __popcll(__ballot(al[1] != 0.f)) + __popcll(__ballot(al[2] != 0.f)) + __popcll(__ballot(al[3] != 0.f));
+                B4_STAT(6, a4);
+            }
+#endif
+            float v[10];
+            const float m0 = q[0] * dx[0], m1 = q[1] * dx[1], m2 = q[2] * dx[2], m3 = q[3] * dx[3];
+            const float sq_ = (q[0] + q[1]) + (q[2] + q[3]);
+            v[0] = (m0 + m1) + (m2 + m3);
+            v[1] = sq_ * dy;
+            v[2] = __builtin_fmaf(m0, dx[0], m1 * dx[1]) + __builtin_fmaf(m2, dx[2], m3 * dx[3]);
+            v[3] = v[0] * dy;
+            v[4] = v[1] * dy;
+            v[5] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+            v[6] = __builtin_fmaf(al[0], gr[0], al[1] * gr[1]) + __builtin_fmaf(al[2], gr[2], al[3] * gr[3]);
+            v[7] = __builtin_fmaf(al[0], gg[0], al[1] * gg[1]) + __builtin_fmaf(al[2], gg[2], al[3] * gg[3]);
+            v[8] = __builtin_fmaf(al[0], gb[0], al[1] * gb[1]) + __builtin_fmaf(al[2], gb[2], al[3] * gb[3]);
+            v[9] = HAS_ZA ? __builtin_fmaf(al[0], gz[0], al[1] * gz[1]) + __builtin_fmaf(al[2], gz[2], al[3] * gz[3]) : 0.0f;
+            float p0, p1, p2;
+            bank_reduce_scatter10(v, p0, p1, p2);
+            float* sl = (float*)((char*)slots + (entry >> 16)) + 3 * k;
+            sl[0] = p0;
+            sl[1] = p1;
+            sl[2] = p2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- flush: 16 lanes per pair, lane c adds float c of the pair's slots (contiguous), in double
+        for (int jb = 0; jb < (int)n_eff; jb += 4) {
+            const int j = jb + (lane >> 4);
+            const bool have = j < (int)n_eff;
+            const uint32_t s0 = have ? hit_off[j] : 0u, s1 = have ? hit_off[j + 1] : 0u;
+            const int cj = (int)(s1 - s0);
+            const int maxc = max(max(__builtin_amdgcn_readlane(cj, 0), __builtin_amdgcn_readlane(cj, 16)),
+                                 max(__builtin_amdgcn_readlane(cj, 32), __builtin_amdgcn_readlane(cj, 48)));
+            const float* sl = slots + (size_t)s0 * SLOTF + (fc < SLOTF ? fc : 0);
+            double acc = 0.0;
+            B4_STAT(5, maxc);
+            for (int i = 0; i < maxc; ++i)
+                if (i < cj) acc += (double)sl[i * SLOTF];
+            const double other = __shfl_xor(acc, 1);
+            if (have && oidx >= 0) {
+                double outv = acc;
+                if (oidx < 2) {
+                    const f4 cn = conic[j];           // (a, b, d) as preprocess wrote them
+                    outv = (double)(oidx == 0 ? cn.x : cn.z) * acc + (double)cn.y * other;
+                } else if (oidx < 5) {
+                    outv = -0.5 * acc;
+                }
+                add_to_row(grad_rows + (size_t)sid[j] * GS_GRAD_ROW, oidx, outv);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -492,9 +855,35 @@ extern "C" int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ra
     if (tile_row_end > tiles_y) tile_row_end = tiles_y;
     if (tile_row_begin >= tile_row_end) return GS_OK;
     const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
-    hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
-                       (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
-                       g_image, g_depth, g_alpha, grad_rows, t_eps);
+    GS_REQUIRE(((uintptr_t)grad_rows & 15) == 0, "grad_rows must be 16-byte aligned");
+    static const int form = [] { const char* e = getenv("GSPLAT_BWD_FORM"); return e ? atoi(e) : 1; }();
+    if (form == 1 && (g_depth || g_alpha))      // first form: lane = pixel, 4 waves per tile
+        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, true>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+                           (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
+                           g_image, g_depth, g_alpha, grad_rows, t_eps);
+    else if (form == 1)
+        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, false>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+                           (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
+                           g_image, g_depth, g_alpha, grad_rows, t_eps);
+    else if (g_depth || g_alpha)
+        hipLaunchKernelGGL((render_bwd4_kernel<GS_BWD4_BATCH, GS_BWD4_CAP, true>), dim3(ntiles), dim3(64), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+                           (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
+                           g_image, g_depth, g_alpha, grad_rows, t_eps);
+    else
+        hipLaunchKernelGGL((render_bwd4_kernel<GS_BWD4_BATCH, GS_BWD4_CAP, false>), dim3(ntiles), dim3(64), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+                           (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
+                           g_image, g_depth, g_alpha, grad_rows, t_eps);
     GS_CHECK_LAUNCH("render_bwd");
     return GS_OK;
 }
+
+#ifdef GS_BWD4_STATS
+extern "C" int gs_debug_bwd4_stats(unsigned long long* host8, int reset) {
+    GS_CHECK_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_bwd4_stats), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        GS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd4_stats), z, sizeof(z)));
+    }
+    return GS_OK;
+}
+#endif

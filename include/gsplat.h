@@ -41,7 +41,7 @@ extern "C" {
 int gs_version(void);            /* 100 = 0.1.0 */
 const char* gs_last_error(void); /* message of this thread's last failing call */
 int gs_tile_size(void);          /* 16: tile edge used by keys and ranges */
-int gs_grad_row_floats(void);    /* 12: floats per per-Gaussian gradient row (see gs_render_bwd) */
+int gs_grad_row_floats(void);    /* 16: floats (4-byte units) per per-Gaussian gradient row (see gs_render_bwd) */
 
 /*
  * Per-Gaussian forward stage.  Replaces GaussianRasterizer.forward's vectorised prologue
@@ -136,10 +136,11 @@ int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32
 
 /*
  * Backward of gs_render_fwd (the reference gets it from torch autograd).  g_image (3,H,W),
- * g_depth / g_alpha (H,W) optional.  grad_rows (N x gs_grad_row_floats() = 12 floats, 16-byte aligned) must be zero on
- * entry and receives, per Gaussian: [0,1] d/d screen mean (pixels), [2] d/d conic a, [3] d/d each
- * off-diagonal conic entry, [4] d/d conic d, [5] d/d opacity, [6..8] d/d rgb, [9] d/d depth.
- * t_eps must equal the forward's.
+ * g_depth / g_alpha (H,W) optional.  grad_rows (N rows of gs_grad_row_floats() = 16 floats = 64 bytes, 16-byte
+ * aligned) must be zero on entry and receives, per Gaussian, five DOUBLES (bytes 0..39): d/d screen mean x, y
+ * (pixels), d/d conic a, d/d each off-diagonal conic entry, d/d conic d -- fp64 atomics, so these sums do not
+ * depend on the order in which the tiles arrive -- and five floats (bytes 40..59): d/d opacity, d/d rgb, d/d depth.
+ * The rows are an opaque hand-over to gs_preprocess_bwd.  t_eps must equal the forward's.
  */
 int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const uint32_t* point_list,
                   const float* aux_rgb, const float* out_depth, const float* out_alpha,

@@ -59,6 +59,17 @@ def check_image(name, got, ref, tol, scale=1.0):
     return float(err.max())
 
 
+def check_image_strict(name, got, ref, tol):
+    """max-abs <= tol at every pixel, no outlier budget: for HIP against the C oracle, whose boxes are bit-identical."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
+    assert np.isfinite(got).all(), f"{name}: non-finite"
+    err = np.abs(got - ref).max() if got.size else 0.0
+    assert err <= tol, f"{name}: max-abs err {err:.3e} > {tol}"
+    return float(err)
+
+
 def check_grad(name, got, ref, rel=TOL_GRAD_REL):
     got = np.asarray(got, dtype=np.float64).reshape(-1)
     ref = np.asarray(ref, dtype=np.float64).reshape(-1)

@@ -7,9 +7,12 @@
 
 One "step" = one pass of the hot path (preprocess -> depth sort -> scan -> keys -> tile sort -> ranges ->
 render forward -> render backward -> preprocess backward) over one synthetic frame per GPU
-(SURVEY.md 8d generator, config 3), inputs already resident in HBM.  With N > 1 every rank
-renders its own camera view of the same replicated Gaussians and the per-Gaussian gradients are
-summed across ranks with a bucketed RCCL all-reduce inside the timed region (weak scaling).
+(SURVEY.md 8d generator, config 3), inputs already resident in HBM.  With N > 1 every rank renders its own
+camera view of the same scene (weak scaling) and the step includes the exchange: --parallel allreduce =
+Gaussians replicated, per-Gaussian gradients summed by a bucketed RCCL all-reduce overlapped with
+preprocess_bwd (the pattern BASELINE.json names); --parallel exchange = Gaussians sharded, splat records and
+gradient rows exchanged by all-to-all; the default (auto) times a few steps of both, runs the faster and
+reports both.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events
 on the launch stream; `cpu_baseline` is the CPU oracle (oracle/gs_oracle.c, a port -- the reference
@@ -54,6 +57,40 @@ def bytes_v1(N, V, D, P, K, tiles, passes):
     }
 
 
+COUNTERS_NOTE = [None]
+
+
+def csrc_sha():
+    """Hash of the kernel sources the in-tree library is built from (the stamp of profiles/counters.json)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_counters(config, t_eps):
+    """profiles/counters.json if it was measured on these kernel sources, this configuration and stop threshold."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    except (OSError, ValueError):
+        COUNTERS_NOTE[0] = "profiles/counters.json missing"
+        return None
+    if os.environ.get("GSPLAT_LIB") or os.environ.get("GSPLAT_BWD_FORM"):
+        COUNTERS_NOTE[0] = "a variant library / kernel form is in use"
+        return None
+    if c.get("csrc_sha") != csrc_sha():
+        COUNTERS_NOTE[0] = f"profiles/counters.json was measured on other kernel sources ({c.get('csrc_sha')} != {csrc_sha()})"
+        return None
+    if c.get("config") != config or abs(float(c.get("t_eps", -1)) - t_eps) > 1e-12:
+        COUNTERS_NOTE[0] = "profiles/counters.json was measured on another configuration"
+        return None
+    return c
+
+
 def bytes_depth_sort(N):
     """Per-Gaussian depth pre-sort (not in the v1 model: it replaces 4 of radix_sort's 6 passes over D
     by 4 passes over N): 4 B histogram read + 8 B read + 8 B written per Gaussian and pass."""
@@ -71,9 +108,14 @@ def main():
     ap.add_argument("--no-exact-mode", action="store_true",
                     help="skip the extra t_eps = 0 timing (profiling runs: keeps one kind of render launch in the trace)")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
-    ap.add_argument("--parallel", default="exchange", choices=["exchange", "allreduce"],
-                    help="N > 1: 'exchange' = Gaussians sharded, splat records / gradient rows exchanged "
-                         "(parallel.SplatExchange); 'allreduce' = Gaussians replicated, gradients all-reduced")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "allreduce", "exchange"],
+                    help="N > 1 training step: 'allreduce' = views sharded, Gaussians replicated, bucketed gradient "
+                         "all-reduce overlapped with preprocess_bwd (parallel.ViewShardedRasterizer: the pattern "
+                         "BASELINE.json names); 'exchange' = Gaussians sharded, splat records / gradient rows exchanged "
+                         "(parallel.SplatExchange); 'auto' = time a few steps of both, run the faster, report both")
+    ap.add_argument("--buckets", type=int, default=4, help="allreduce: Gaussian ranges per backward (one all-reduce each)")
+    ap.add_argument("--no-next-rows", action="store_true",
+                    help="skip the loss / optimizer / PLY / k-NN legs (counter runs: only the path's kernels in the trace)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 code path with several ranks on ONE GPU (timings meaningless)")
     ap.add_argument("--forward-only", action="store_true", help="render only (implied by the 4K config)")
@@ -82,6 +124,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (process group, collectives) even with one rank")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line: everything libraries print there (RCCL's version banner, gloo's connection
+    # notes) goes to stderr instead; the JSON line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.watchdog == 0 and world > 1:
@@ -121,7 +169,6 @@ def main():
     t_eps = impl.DEFAULT_T_EPS if args.t_eps is None else args.t_eps
     scene = syn.make_scene(N, K, H, W, seed=0)
     forward_only = "forward_only" in args.config or args.forward_only
-    exchange = multi and args.parallel == "exchange" and not forward_only
     names = ("means3D", "shs", "opacities", "scales", "rotations")
 
     def make_settings(view):
@@ -136,23 +183,26 @@ def main():
     settings = make_settings(views[rank])
     G = scene.G.to(dev)
     rast = dgr.GaussianRasterizer(settings, t_eps=t_eps)
-    params, all_settings, ex, reducer = {}, None, None, None
+    params, all_settings, ex, vs_rast = {}, None, None, None
+    mode = "single"          # single | tile_rows | allreduce | exchange
 
-    def setup():
-        nonlocal params, all_settings, ex, reducer
-        params, all_settings, ex, reducer = {}, None, None, None
-        if exchange:      # this rank owns Gaussians [lo, hi)
+    def setup(new_mode):
+        nonlocal params, all_settings, ex, vs_rast, mode
+        params, all_settings, ex, vs_rast, mode = {}, None, None, None, new_mode
+        torch.cuda.empty_cache()
+        if mode == "exchange":      # this rank owns Gaussians [lo, hi)
             lo, hi = par.tile_row_band(N, rank, world)
             params = {k: getattr(scene, k)[lo:hi].to(dev).requires_grad_(True) for k in names}
             all_settings = [make_settings(v) for v in views]
             ex = par.SplatExchange(hi - lo, device=dev)
         else:
             params = {k: getattr(scene, k).to(dev).requires_grad_(True) for k in names}
-            if multi:
-                reducer = par.GradReducer(list(params.values()), bucket_bytes=int(args.bucket_mb * 2 ** 20))
+            if mode == "allreduce":
+                vs_rast = par.ViewShardedRasterizer(settings, t_eps=t_eps, num_buckets=args.buckets,
+                                                    force_collectives=args.force_dist)
 
     def step():
-        if forward_only and multi:
+        if mode == "tile_rows":
             # large-frame inference: this rank renders its band of tile rows, rank 0 assembles the frame
             with torch.no_grad():
                 band = par.render_band(settings, rank, world, t_eps=t_eps, means3D=params["means3D"], shs=params["shs"],
@@ -166,7 +216,7 @@ def main():
                             rotations=params["rotations"], cov3D_precomp=None)[1]
         for p in params.values():
             p.grad = None
-        if exchange:
+        if mode == "exchange":
             means2D = torch.zeros((world, params["means3D"].shape[0], 3), device=dev, requires_grad=True)
             image, radii, depth, alpha = ex.rasterize(all_settings, params["means3D"], means2D=means2D,
                                                       shs=params["shs"], opacities=params["opacities"],
@@ -175,13 +225,12 @@ def main():
             image.backward(G)
             return radii
         means2D = torch.zeros_like(params["means3D"], requires_grad=True)
-        image, radii, depth, alpha = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
-                                          colors_precomp=None, opacities=params["opacities"],
-                                          scales=params["scales"], rotations=params["rotations"],
-                                          cov3D_precomp=None)
+        r = vs_rast if mode == "allreduce" else rast      # allreduce: the gradients arrive summed over the ranks
+        image, radii, depth, alpha = r(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                       colors_precomp=None, opacities=params["opacities"],
+                                       scales=params["scales"], rotations=params["rotations"],
+                                       cov3D_precomp=None)
         image.backward(G)
-        if reducer is not None:
-            reducer.all_reduce_grads()
         return radii
 
     def fence():
@@ -190,23 +239,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    setup()
-    if exchange:
-        # first use of the all-to-all path on this machine: if RCCL refuses it on any rank, every rank
-        # falls back to the replicated / all-reduce step (reported as such in config.parallelism)
-        ok = 1
-        try:
-            step()
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] rank {rank}: splat exchange failed ({type(e).__name__}: {e}); using --parallel allreduce",
-                  file=sys.stderr, flush=True)
-            ok = 0
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            exchange = False
-            setup()
+    probe = None
+    if not multi:
+        setup("single")
+    elif forward_only:
+        setup("tile_rows")
+    elif args.parallel != "auto":
+        setup(args.parallel)          # an explicit choice that fails ends the run with a non-zero exit status
+    else:
+        # N > 1 over xGMI has never been run by the builder (one-GPU boxes): time a few steps of both partitionings,
+        # run the timed region on the faster, report both.  A mode that raises is reported as such; if both do, exit.
+        probe = {}
+        for m in ("allreduce", "exchange"):
+            ok = 1
+            try:
+                setup(m)
+                for _ in range(3):
+                    step()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                fence()
+                ms = (time.perf_counter() - t0) / 5 * 1e3
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: mode {m} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                ok, ms = 0, float("inf")
+            t = torch.tensor([float(ok), -ms if ok else -1e30], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)            # all ranks ok, and the slowest rank's time
+            probe[m] = round(-float(t[1].item()), 4) if int(t[0].item()) == 1 else "failed"
+        good = {m: v for m, v in probe.items() if v != "failed"}
+        if not good:
+            raise SystemExit("[bench] both multi-GPU modes failed (see stderr of the ranks)")
+        setup(min(good, key=good.get))
+    exchange = mode == "exchange"
     for _ in range(args.warmup):
         step()
     fence()
@@ -236,7 +302,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    frames_per_step = 1 if (forward_only and multi) else world      # tile-row sharding splits ONE frame
+    frames_per_step = 1 if mode == "tile_rows" else world      # tile-row sharding splits ONE frame
     value = frames_per_step * W * H / (dt / args.steps) / 1e6
 
     if rank == 0:
@@ -261,38 +327,51 @@ def main():
         b["depth_sort"] = bytes_depth_sort(N)
         dom_bytes = b[stage_of[dominant]]
         achieved = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc cannot run inside this process:
-        # they are collected by tools/pmc_hbm.sh on this same command and committed under profiles/)
-        traffic, traffic_src = None, None
-        if args.config == "config3_garden_3M_sh3_1297x840" and args.t_eps is None:
-            try:
-                tab = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-                traffic = tab["kernels"][dominant + "_kernel"]["traffic_bytes"]
-                traffic_src = tab["source"]
-            except (OSError, KeyError, ValueError):
-                pass
+        # every stage of the path, timed by HIP events in THIS run (dominant: mean over the timed region; the
+        # others: mean over the three instrumented steps before it); algorithmic bytes from the v1 model
+        table = {}
+        for st_name, ms in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
+            if st_name in stage_of and not (forward_only and st_name.endswith("_bwd")):
+                nb = b[stage_of[st_name]]
+                table[st_name] = {"algorithmic_bytes": nb, "ms": round(ms, 4), "GBps": round(nb / (ms * 1e-3) / 1e9, 1),
+                                  "frac_of_hbm_peak": round(nb / (ms * 1e-3) / HBM_PEAK, 4)}
+        # Hardware counters cannot be read from inside this process: tools/pmc_collect.sh runs this same command under
+        # rocprofv3 --pmc (one pass per counter group) and tools/make_counters.py writes profiles/counters.json,
+        # stamped with a hash of the kernel sources.  A stamp that does not match the sources this run was built
+        # from means the numbers belong to other kernels: they are then withheld (null), not repeated.
+        cnt = load_counters(args.config, t_eps)
+        ck = (cnt or {}).get("kernels", {}).get(dominant)
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
+                    "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 4),
+                    "traffic": ck.get("hbm_traffic_bytes") if ck else None,
+                    "traffic_source": cnt["source"] if ck else ("withheld: " + COUNTERS_NOTE[0] if COUNTERS_NOTE[0] else None),
                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(stage_ms[dominant], 4),
-                    "limiter": ("VALU issue: 22 of the backward loop's 59 vector instructions are DPP adds, which issue "
-                                "at half rate (4.15 cycles measured, profiles/r1f_valu_issue_rates.txt); SQ_ACTIVE_INST_VALU "
-                                "x4 / SIMD cycles = 87 % in render_bwd (profiles/r1d_pmc_sq_counters.txt); HBM accounting "
-                                "kept as the task prescribes")
-                    if dominant.startswith("render") else "HBM / latency (see DESIGN.md section 4)"}
-        # secondary bound: VALU issue rate of the render kernels, from the SQ counters under profiles/
-        try:
-            vt = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
-            if dominant in vt["kernels"] and args.config == "config3_garden_3M_sh3_1297x840" and args.t_eps is None:
-                rate = vt["kernels"][dominant]["valu_wave_insts"] / (stage_ms[dominant] * 1e-3)
-                peak = vt["kernels"][dominant].get("peak_wave_insts_per_s", vt["peak_wave_insts_per_s"])
+                    "kernels": table}
+        if ck:
+            secs = stage_ms[dominant] * 1e-3
+            if ck.get("valu_wave_insts") and ck.get("mean_issue_cycles"):
+                peak = 256 * 4 * 2.4e9 / ck["mean_issue_cycles"]
+                rate = ck["valu_wave_insts"] / secs
                 roofline["valu"] = {"achieved_G_wave_insts_per_s": round(rate / 1e9, 1),
-                                    "peak_G_wave_insts_per_s": round(peak / 1e9, 1),
-                                    "frac": round(rate / peak, 4), "source": vt["source"],
-                                    "peak_note": "issue peak for this kernel's instruction mix, from measured "
-                                                 "per-instruction issue costs (profiles/valu_insts.json)"}
-        except (OSError, KeyError, ValueError):
-            pass
+                                    "peak_G_wave_insts_per_s": round(peak / 1e9, 1), "frac": round(rate / peak, 4),
+                                    "valu_wave_insts_per_launch": ck["valu_wave_insts"],
+                                    "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / mean issue cycles of the visit loop's "
+                                                 "instruction mix (profiles/r1f_valu_issue_rates.txt)"}
+            if ck.get("write_size_bytes") is not None and dominant == "render_bwd":
+                roofline["atomics"] = {"write_bytes_per_launch": ck["write_size_bytes"],
+                                       "achieved_GBps": round(ck["write_size_bytes"] / secs / 1e9, 1), "peak_GBps": 1300.0,
+                                       "frac": round(ck["write_size_bytes"] / secs / 1.3e12, 4),
+                                       "note": "render_bwd writes HBM only through its per-(tile, Gaussian) row atomics "
+                                               "(WRITE_SIZE); peak = the guide's ~1.3 TB/s float-atomic rate"}
+            if ck.get("lds_bank_conflict_cycles") is not None and ck.get("lds_active_cycles"):
+                roofline["lds"] = {"bank_conflict_cycles": ck["lds_bank_conflict_cycles"],
+                                   "active_cycles": ck["lds_active_cycles"],
+                                   "conflict_frac": round(ck["lds_bank_conflict_cycles"] / ck["lds_active_cycles"], 4)}
+            if ck.get("valu_busy_frac") is not None:
+                roofline["limiter"] = (f"VALU issue: SQ_ACTIVE_INST_VALU x 4 / SIMD cycles = {ck['valu_busy_frac']:.0%} in "
+                                       f"{dominant} ({cnt['source']}); HBM accounting kept as the task prescribes")
+        if "limiter" not in roofline:
+            roofline["limiter"] = "see DESIGN.md section 4 (no counters for this build / configuration)"
         out = {
             "metric": "Mpix/s fwd+bwd @3M Gaussians SH3" if args.config.startswith("config3") else "Mpix/s " + args.config, "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -302,16 +381,25 @@ def main():
             "config": {"workload": args.config, "gaussians": N, "sh_coeffs": K, "width": W, "height": H,
                        "drawn": V, "tile_pairs": D, "t_eps": t_eps,
                        "views_per_step": frames_per_step,
-                       "parallelism": "single" if not multi else f"tile_rows{world}" if forward_only else
-                       (f"views{world}+gaussians_sharded{world}(splat exchange)" if exchange else
-                        f"views{world}+gaussians_replicated(grad all-reduce)")},
+                       "parallelism": {"single": "single", "tile_rows": f"tile_rows{world}",
+                                       "exchange": f"views{world}+gaussians_sharded{world}(splat exchange)",
+                                       "allreduce": f"views{world}+gaussians_replicated(bucketed grad all-reduce "
+                                                    f"overlapped with preprocess_bwd, {args.buckets} buckets)"}[mode],
+                       "parallel_arg": args.parallel},
             "roofline": roofline,
             "frame_hbm": {"algorithmic_bytes_v1": frame_bytes,
                           "frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 4)},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         }
-        if multi:   # several launches of a stage per step (one per view): mean per launch above, launches here
+        if probe is not None:
+            out["parallel_probe_ms_per_step"] = probe
+        if multi:   # several launches of a stage per step (one per view / bucket): mean per launch above, launches here
             out["stage_launches_per_step"] = {k: round(v, 2) for k, v in calls_per_step.items() if v != 1.0}
+            if mode == "allreduce":
+                n_f = sum(int(p[0].numel()) for p in params.values())
+                out["allreduce_bytes_per_rank_and_step"] = {
+                    "payload": 4 * n_f * N, "note": f"{n_f} fp32 gradients per Gaussian, all {N} Gaussians, "
+                                                    f"{args.buckets} buckets launched as gs_preprocess_bwd finishes each range"}
             if exchange:
                 n_loc = params["means3D"].shape[0]
                 out["exchange_bytes_per_rank_and_step"] = {
@@ -342,7 +430,7 @@ def main():
             out["exact_mode"] = {"t_eps": 0.0, "ms_per_step": round(ms_exact, 4),
                                  "value": round(W * H / (ms_exact * 1e-3) / 1e6, 2), "unit": "Mpix/s",
                                  "note": "no early termination; 10 steps, wall time"}
-        if world == 1 and not forward_only:
+        if world == 1 and not forward_only and not args.no_next_rows:
             out["next_rows"] = {"l1_ssim_loss": bench_loss(impl, H, W, dev),
                                 "adam_densify_step": bench_adam(impl, params, radii, dev),
                                 "ply_unpack": bench_ply(N, K, dev),
@@ -350,7 +438,8 @@ def main():
                                 "training_iteration": bench_iteration(impl, rast, scene, dev)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,8 +34,40 @@ def tile_row_band(tile_rows: int, rank: int, world: int):
     return begin, begin + q + (1 if rank < r else 0)
 
 
+def _all_reduce_sum(tensors, group, async_op: bool):
+    """SUM all-reduce of several tensors, in place.  RCCL: one grouped launch (a single ncclGroup) on RCCL's own
+    stream, ordered after what the current stream holds at this point; async_op returns a handle for _wait().
+    gloo (tests and rehearsals only: several ranks on one GPU, or CPU tensors): device tensors are staged through
+    the host by hand, one at a time -- gloo's own device path (pinned staging allocated per call, a worker
+    thread synchronising side streams) stalls for minutes with two busy processes on one GPU."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if not tensors:
+        return None
+    if dist.get_backend(group) == "gloo":
+        for t in tensors:
+            if t.is_cuda:
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return None
+    if len(tensors) == 1:
+        w = dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return w if async_op else None
+    cm_factory = getattr(dist.distributed_c10d, "_coalescing_manager", None)
+    if cm_factory is not None:
+        with cm_factory(group=group, device=tensors[0].device, async_ops=async_op) as cm:
+            for t in tensors:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return cm if async_op else None
+    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op) for t in tensors]
+    return works if async_op else None
+
+
 class GradReducer:
-    """Bucketed all-reduce (SUM, optionally / world) of the .grad of replicated per-Gaussian parameters."""
+    """Bucketed all-reduce (SUM, optionally / world) of the .grad of replicated per-Gaussian parameters, after the
+    backward has finished (ViewShardedRasterizer below overlaps the same exchange with the backward)."""
 
     def __init__(self, params: Iterable[torch.Tensor], bucket_bytes: int = 64 << 20, average: bool = False,
                  group: Optional[dist.ProcessGroup] = None):
@@ -55,7 +87,6 @@ class GradReducer:
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
         works = []
-        overlap = dist.get_backend(self.group) == "nccl"     # several buckets in flight only on RCCL's own stream
         for p in self.params:
             if p.grad is None:
                 continue
@@ -67,13 +98,9 @@ class GradReducer:
                 if _DEBUG:
                     print(f"[GradReducer] rank {dist.get_rank(self.group)}: {tuple(b.shape)} {b.dtype} {b.device} "
                           f"contiguous={b.is_contiguous()} offset={b.storage_offset()}", flush=True)
-                w = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=overlap)
-                if overlap:
-                    works.append(w)
-                elif b.is_cuda:
-                    torch.cuda.synchronize(b.device)   # gloo on device tensors (rehearsals only): one at a time
+                works.append(_all_reduce_sum([b], self.group, async_op=True))   # several buckets in flight on RCCL's stream
         for w in works:
-            w.wait()
+            _wait(w)
         if self.average:
             ws = dist.get_world_size(self.group)
             for p in self.params:
@@ -156,8 +183,10 @@ def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_rows, in_rows, gr
 
 def _wait(work):
     """Make the current stream wait for an asynchronous collective (no host block with RCCL)."""
-    if work is not None:
-        work.wait()
+    if work is None:
+        return
+    for w in (work if isinstance(work, (list, tuple)) else [work]):
+        w.wait()
 
 
 class _RasterizeSharded(torch.autograd.Function):
@@ -165,7 +194,7 @@ class _RasterizeSharded(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                views, t_eps, counts, group):
+                views, t_eps, counts, group, need_grad=True):
         from . import rasterizer as R
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         dev = means3D.device
@@ -204,8 +233,6 @@ class _RasterizeSharded(torch.autograd.Function):
             state = R.bin_splats(mine, splat, None, None, dkeys, ids, rects, before_scan=lambda: _wait(w_rects))
             with _stage("exchange_fwd_wait"):
                 _wait(w_splat)
-            need_grad = any(t is not None and t.requires_grad for t in
-                            (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
             band = R._band(mine, None)
             image, depth, alpha, aux, rows = R.render_forward(mine, splat, state.ranges, state.point_list, need_grad,
                                                               t_eps, band)
@@ -273,7 +300,7 @@ class _RasterizeSharded(torch.autograd.Function):
             if needs[1] and ctx.means2D_shape is not None:
                 acc[1] = torch.stack(g_m2d) if per_view_means2D else \
                     torch.zeros(ctx.means2D_shape, dtype=torch.float32, device=dev)
-        return (*acc, None, None, None, None)
+        return (*acc, None, None, None, None, None)
 
 
 class SplatExchange:
@@ -345,6 +372,153 @@ class SplatExchange:
         scales = R._prep(scales, "scales", (3,), dev)
         rotations = R._prep(rotations, "rotations", (4,), dev)
         cov3D_precomp = R._prep(cov3D_precomp, "cov3D_precomp", (6,), dev)
+        need_grad = R.wants_grad(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
         return _RasterizeSharded.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, list(views), R.DEFAULT_T_EPS if t_eps is None else t_eps,
-                                       list(self.counts), self.group)
+                                       list(self.counts), self.group, need_grad)
+
+
+# ---------------------------------------------------------------------------------------------------
+# View-sharded training step: Gaussians replicated, gradient all-reduce overlapped with the backward
+# ---------------------------------------------------------------------------------------------------
+def bucket_ranges(n: int, num_buckets: int, align: int = 256):
+    """[begin, end) Gaussian ranges of at most num_buckets buckets; boundaries are multiples of `align` (whole
+    workgroups of gs_preprocess_bwd) except the last end."""
+    if n <= 0:
+        return []
+    per = -(-n // max(1, num_buckets))
+    per = -(-per // align) * align
+    return [(b, min(b + per, n)) for b in range(0, n, per)]
+
+
+class _RasterizeReplicated(torch.autograd.Function):
+    """rasterizer.rasterize_gaussians whose backward runs gs_preprocess_bwd per Gaussian range and all-reduces each
+    range's gradients as soon as its launch is queued (see ViewShardedRasterizer)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                settings, t_eps, need_grad, owner):
+        from . import rasterizer as R
+        dev = means3D.device
+        with torch.cuda.device(dev):
+            band = R._band(settings, None)
+            state = R.preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                         colors_precomp, None)
+            image, depth, alpha, aux, rows = R.render_forward(settings, state.splat, state.ranges, state.point_list,
+                                                              need_grad, t_eps, band)
+        ctx.rows, ctx.settings, ctx.t_eps, ctx.band, ctx.owner = rows, settings, float(t_eps), band, owner
+        ctx.set_materialize_grads(False)
+        ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
+        ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
+        saved = [means3D, opacities, state.splat, state.radii, state.point_list, state.ranges, depth, alpha]
+        saved += [t for t in (shs, colors_precomp, scales, rotations, cov3D_precomp) if t is not None]
+        ctx.has_aux = aux is not None
+        if aux is not None:
+            saved.append(aux)
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(state.radii)
+        return image, state.radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_image, g_radii, g_depth, g_alpha):
+        from . import rasterizer as R
+        saved = list(ctx.saved_tensors)
+        means3D, opacities, splat, radii, point_list, ranges, depth, alpha = saved[:8]
+        rest = saved[8:]
+        shs, colors_precomp, scales, rotations, cov3D_precomp = [rest.pop(0) if h else None for h in ctx.has]
+        if not ctx.has_aux:
+            raise RuntimeError("backward called but no input required grad in forward")
+        aux = rest.pop(0)
+        owner, settings = ctx.owner, ctx.settings
+        dev = means3D.device
+        N = means3D.shape[0]
+        needs = list(ctx.needs_input_grad[:8])
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rows, ctx.rows = ctx.rows, None
+            rows = R.render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_image, g_depth, g_alpha,
+                                     rows, ctx.t_eps, ctx.band)
+            # full-size destinations, in the order of GaussianRasterizer.forward's arguments; means2D's gradient is a
+            # per-view statistic (densification) and is NOT summed over ranks
+            per_row = (means3D, None, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+            full = [torch.empty_like(t) if (t is not None and needs[i]) else None for i, t in enumerate(per_row)]
+            if needs[1] and ctx.means2D_shape is not None:
+                full[1] = torch.empty((N, 3), **f32) if ctx.means2D_shape == (N, 3) else torch.zeros(ctx.means2D_shape, **f32)
+            m2d_rows = full[1] is not None and ctx.means2D_shape == (N, 3)
+            reduce_now = owner.world > 1 or owner.force_collectives
+            works = []
+            # lean per-range launches: the camera tensors are converted once and the C-ABI is called on base pointers
+            # + row offsets (the host must queue 2 kernels and one grouped all-reduce per range faster than the GPU
+            # finishes them, or the overlap is lost to launch gaps)
+            lib = R._lib.load()
+            K = shs.shape[1] if shs is not None else 0
+            cam = [R._camera_tensor(getattr(settings, k), n, k, dev) for k, n in
+                   (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
+            cam_p = [R._ptr(t) for t in cam]
+            st = R._stream()
+            H, W = settings.image_height, settings.image_width
+
+            def at(t, b):
+                return None if t is None else R.C.c_void_p(t.data_ptr() + b * t.stride(0) * 4)
+
+            g_m3, g_m2, g_sh, g_col, g_op, g_sc, g_rot, g_cov = full
+            if not m2d_rows:
+                g_m2 = None
+            for (b, e) in bucket_ranges(N, owner.num_buckets):
+                with _stage("preprocess_bwd"):
+                    R._lib.check(lib.gs_preprocess_bwd(
+                        e - b, K, settings.sh_degree, H, W, *cam_p, at(means3D, b), at(scales, b), at(rotations, b),
+                        at(cov3D_precomp, b), at(shs, b), at(colors_precomp, b), at(radii, b), at(rows, b),
+                        at(g_m3, b), at(g_m2, b), at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b), at(g_sh, b),
+                        at(g_col, b), 0, st), "gs_preprocess_bwd")
+                if reduce_now:      # queued behind this range's launches on RCCL's stream; the next range's kernels overlap it
+                    with _stage("allreduce_launch"):
+                        works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
+                                                     owner.group, async_op=True))
+            with _stage("allreduce_wait"):
+                for w in works:
+                    _wait(w)
+            if owner.average and owner.world > 1:
+                for i, t in enumerate(full):
+                    if t is not None and i != 1:
+                        t.div_(owner.world)
+        return (*full, None, None, None, None)
+
+
+class ViewShardedRasterizer:
+    """The training pattern BASELINE.json's north_star names: every rank holds ALL Gaussians
+    and renders its own camera view; the one exchange step is the SUM of the per-Gaussian gradients (59 floats per
+    Gaussian at SH degree 3), bucketed along the Gaussian axis and overlapped with the backward.  No counterpart in
+    the reference (one view per iteration on one device, train.py:129-135); equal to sequential accumulation of the
+    same views on one device up to fp32 summation order.
+
+    The backward runs gs_preprocess_bwd once per bucket -- the C-ABI takes base pointers and a count, so a bucket
+    is a row slice of every per-Gaussian tensor -- and launches that bucket's all-reduce (one grouped RCCL call
+    over its slices of the gradient tensors) right after its kernels are queued: RCCL's stream starts on bucket b
+    while this stream computes bucket b + 1, and only the last bucket's transfer is exposed.  The gradients that
+    autograd hands to the parameters are already summed over the ranks (divided by the world size if `average`).
+    means2D's gradient (the densification statistic, per view) and radii are not exchanged: reduce them with
+    reduce_densify_stats after folding them into the per-Gaussian statistics.
+
+    Usable as a drop-in for GaussianRasterizer(raster_settings): same call signature, same 4-tuple."""
+
+    def __init__(self, raster_settings, t_eps=None, num_buckets: int = 4, average: bool = False,
+                 group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False):
+        from .rasterizer import DEFAULT_T_EPS
+        self.raster_settings = raster_settings
+        self.t_eps = DEFAULT_T_EPS if t_eps is None else t_eps
+        self.num_buckets = int(num_buckets)
+        self.average = average
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # world 1 has nothing to exchange; force_collectives issues the (self-)all-reduces anyway (bench.py --force-dist)
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()
+
+    def __call__(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
+                 rotations=None, cov3D_precomp=None, cov3Ds_precomp=None):
+        from . import rasterizer as R
+        m3, m2, sh, col, op, sc, rot, cov = R.check_inputs(self.raster_settings, means3D, means2D, shs, colors_precomp,
+                                                           opacities, scales, rotations, cov3D_precomp, cov3Ds_precomp)
+        need_grad = R.wants_grad(m3, m2, sh, col, op, sc, rot, cov)
+        return _RasterizeReplicated.apply(m3, m2, sh, col, op, sc, rot, cov, self.raster_settings, self.t_eps,
+                                          need_grad, self)

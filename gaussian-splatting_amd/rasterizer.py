@@ -340,10 +340,13 @@ def render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_im
 
 
 def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows,
-                        needs, means2D_shape, accumulate_into=None):
+                        needs, means2D_shape, accumulate_into=None, out=None):
     """gs_preprocess_bwd on the current stream.  `needs` = 8 flags in the order of GaussianRasterizer.forward's
     arguments; returns the 8 gradients (None where not needed).  accumulate_into = the 8-tuple a previous
-    call returned: this view's gradients are added into those tensors (means2D's, per view, is fresh)."""
+    call returned: this view's gradients are added into those tensors (means2D's, per view, is fresh).
+    out = an 8-tuple of preallocated destinations (None where not needed) that this call OVERWRITES: row
+    slices of full-size gradient tensors when the chain rule runs per Gaussian range (every per-Gaussian
+    argument is then the same row slice; parallel.ViewShardedRasterizer)."""
     lib = _lib.load()
     dev = means3D.device
     N = means3D.shape[0]
@@ -356,6 +359,13 @@ def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs
     g_means2D = torch.empty(means2D_shape, **f32) if (needs[1] and means2D_shape == (N, 3)) else None
     if accumulate_into is not None:
         g_means3D, _, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov = accumulate_into
+    elif out is not None:
+        g_means3D, o_m2d, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov = out
+        if o_m2d is not None:
+            g_means2D = o_m2d
+        for t in out:
+            if t is not None and (not t.is_contiguous() or t.shape[0] != N or t.dtype != torch.float32):
+                raise ValueError("preprocess_backward: out tensors must be contiguous float32 with N rows")
     else:
         g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
         g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
@@ -380,14 +390,12 @@ def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                settings, t_eps, tile_rows=None):
+                settings, t_eps, tile_rows=None, need_grad=True):
         dev = means3D.device
         with torch.cuda.device(dev):
             band = _band(settings, tile_rows)
             state = preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
                                        colors_precomp, tile_rows)
-            need_grad = any(t is not None and t.requires_grad for t in
-                            (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
             image, depth, alpha, aux, rows = render_forward(settings, state.splat, state.ranges, state.point_list,
                                                             need_grad, t_eps, band)
         ctx.rows = rows
@@ -425,15 +433,23 @@ class _RasterizeGaussians(torch.autograd.Function):
                                    rows, ctx.t_eps, ctx.band)
             grads = preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
                                         radii, rows, ctx.needs_input_grad, ctx.means2D_shape)
-        return (*grads, None, None, None)
+        return (*grads, None, None, None, None)
+
+
+def wants_grad(*tensors) -> bool:
+    """Will a backward follow?  Grad mode is always off inside autograd.Function.forward, so this is asked by the
+    caller, outside: under torch.no_grad() the forward then skips the backward's buffers (3 H W floats of aux, the
+    clear of N 64-byte gradient rows)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                         raster_settings, t_eps: float = DEFAULT_T_EPS, tile_rows=None):
     """tile_rows = (begin, end): render only that band of 16-pixel tile rows (pixels outside it are
     left unwritten) -- the unit of work of tile-row sharded inference."""
+    need_grad = wants_grad(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
     return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                     cov3D_precomp, raster_settings, t_eps, tile_rows)
+                                     cov3D_precomp, raster_settings, t_eps, tile_rows, need_grad)
 
 
 class GaussianRasterizer(nn.Module):
@@ -448,37 +464,44 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
                 rotations=None, cov3D_precomp=None, cov3Ds_precomp=None):
-        rs = self.raster_settings
-        if cov3D_precomp is None:
-            cov3D_precomp = cov3Ds_precomp          # the reference's own spelling (:85, :637)
-        if (shs is None) == (colors_precomp is None):
-            raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
-        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
-                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
-            raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        if opacities is None:
-            raise ValueError("opacities is required")
-        if not torch.is_tensor(means3D) or means3D.dim() != 2 or means3D.shape[1] != 3:
-            raise ValueError("means3D must be a (N,3) tensor")
-        dev = means3D.device
-        N = means3D.shape[0]
-        if shs is not None:
-            if shs.dim() != 3 or shs.shape[2] != 3:
-                raise ValueError(f"shs must be (N,K,3), got {tuple(shs.shape)}")
-            if (rs.sh_degree + 1) ** 2 > shs.shape[1]:
-                raise ValueError(f"sh_degree {rs.sh_degree} needs {(rs.sh_degree + 1) ** 2} coefficients, shs has {shs.shape[1]}")
-        means3D = _prep(means3D, "means3D", (3,), dev)
-        shs = _prep(shs, "shs", None, dev)
-        colors_precomp = _prep(colors_precomp, "colors_precomp", (3,), dev)
-        opacities = _prep(opacities.reshape(N, 1) if opacities.dim() == 1 else opacities, "opacities", (1,), dev)
-        scales = _prep(scales, "scales", (3,), dev)
-        rotations = _prep(rotations, "rotations", (4,), dev)
-        cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", (6,), dev)
-        for name, t in (("shs", shs), ("colors_precomp", colors_precomp), ("opacities", opacities),
-                        ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp)):
-            if t is not None and t.shape[0] != N:
-                raise ValueError(f"{name} has {t.shape[0]} rows, means3D has {N}")
-        if not (0 <= rs.sh_degree <= 3):
-            raise ValueError(f"sh_degree must be 0..3, got {rs.sh_degree}")
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, rs, self.t_eps, self.tile_rows)
+        args = check_inputs(self.raster_settings, means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                            cov3D_precomp, cov3Ds_precomp)
+        return rasterize_gaussians(*args, self.raster_settings, self.t_eps, self.tile_rows)
+
+
+def check_inputs(rs, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
+                 rotations=None, cov3D_precomp=None, cov3Ds_precomp=None):
+    """Argument checks of GaussianRasterizer.forward (the reference's adapter calls it by keyword,
+    gaussian_renderer/__init__.py:623-638) -> the eight tensors, contiguous float32 on one device."""
+    if cov3D_precomp is None:
+        cov3D_precomp = cov3Ds_precomp          # the reference's own spelling (:85, :637)
+    if (shs is None) == (colors_precomp is None):
+        raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    if opacities is None:
+        raise ValueError("opacities is required")
+    if not torch.is_tensor(means3D) or means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise ValueError("means3D must be a (N,3) tensor")
+    dev = means3D.device
+    N = means3D.shape[0]
+    if shs is not None:
+        if shs.dim() != 3 or shs.shape[2] != 3:
+            raise ValueError(f"shs must be (N,K,3), got {tuple(shs.shape)}")
+        if (rs.sh_degree + 1) ** 2 > shs.shape[1]:
+            raise ValueError(f"sh_degree {rs.sh_degree} needs {(rs.sh_degree + 1) ** 2} coefficients, shs has {shs.shape[1]}")
+    means3D = _prep(means3D, "means3D", (3,), dev)
+    shs = _prep(shs, "shs", None, dev)
+    colors_precomp = _prep(colors_precomp, "colors_precomp", (3,), dev)
+    opacities = _prep(opacities.reshape(N, 1) if opacities.dim() == 1 else opacities, "opacities", (1,), dev)
+    scales = _prep(scales, "scales", (3,), dev)
+    rotations = _prep(rotations, "rotations", (4,), dev)
+    cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", (6,), dev)
+    for name, t in (("shs", shs), ("colors_precomp", colors_precomp), ("opacities", opacities),
+                    ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp)):
+        if t is not None and t.shape[0] != N:
+            raise ValueError(f"{name} has {t.shape[0]} rows, means3D has {N}")
+    if not (0 <= rs.sh_degree <= 3):
+        raise ValueError(f"sh_degree must be 0..3, got {rs.sh_degree}")
+    return means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp

@@ -300,7 +300,8 @@ static int ply_launch(bool pack, const GsPlyLayout* layout, void* records, float
     GS_REQUIRE(records && ((uintptr_t)records & 3) == 0, "records must be a 4-byte aligned device pointer");
     GS_REQUIRE(!pack || (xyz && f_dc && opacity && scaling && rotation && (f_rest || D.rest == 0)), "pack needs every parameter");
     // waves per workgroup: as many as keep the staged records within 64 KB of LDS (4 for a degree-3 model)
-    int wpb = (int)(65536 / ((size_t)64 * D.stride_dw * 4));
+    // 64 KB of LDS per workgroup: the dynamic staging area shares it with the static offset table (s_off_rest)
+    int wpb = (int)((65536 - sizeof(int) * GS_PLY_MAX_REST) / ((size_t)64 * D.stride_dw * 4));
     wpb = wpb > PLY_THREADS / 64 ? PLY_THREADS / 64 : wpb;
     const size_t lds_bytes = (size_t)wpb * 64 * D.stride_dw * 4;
     const long long waves = (N + 63) / 64;

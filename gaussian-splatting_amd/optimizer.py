@@ -50,18 +50,53 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False)
 
     @torch.no_grad()
+    def update_densify_stats(self, viewspace_grad=None, radii=None, xyz_gradient_accum=None, denom=None,
+                             max_radii2D=None):
+        """The statistics of train.py:184-193 / scene/gaussian_model.py:701-713 alone, no parameter update
+        (gs_adam_densify_step with zero groups: one small launch).
+
+        This is the call for iterations on which the reference densifies, prunes or resets between the
+        statistics and the step (train.py:196-214): densify() consumes, resizes and zeroes the accumulators,
+        so they must be up to date BEFORE it -- and after it radii / viewspace_grad have the old N while the
+        accumulators have the new one, so they cannot be folded into step() on such an iteration."""
+        if radii is None:
+            raise ValueError("update_densify_stats needs radii (the rasterizer's second output)")
+        self._launch([], self._check_stats(viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D), radii.device)
+
+    @staticmethod
+    def _check_stats(viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D):
+        if not radii.is_cuda or radii.dtype != torch.int32:
+            raise RuntimeError("radii must be an int32 tensor on the GPU (the rasterizer's second output)")
+        radii = radii.contiguous()
+        views = 1 if radii.dim() == 1 else radii.shape[0]
+        n = radii.shape[-1]
+        if viewspace_grad is not None:
+            viewspace_grad = viewspace_grad.contiguous()
+            if viewspace_grad.numel() != views * n * 3 or viewspace_grad.dtype != torch.float32:
+                raise ValueError("viewspace_grad must be float32 with shape (N,3) or (views,N,3) matching radii")
+        for name, t_ in (("xyz_gradient_accum", xyz_gradient_accum), ("denom", denom), ("max_radii2D", max_radii2D)):
+            if t_ is not None and (t_.numel() != n or t_.dtype != torch.float32 or not t_.is_contiguous()
+                                   or not t_.is_cuda):
+                raise ValueError(f"{name} must be a contiguous float32 GPU tensor with N = {n} elements (radii has "
+                                 f"{n}: were the Gaussians densified or pruned since the render?)")
+        return (n, views, viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D)
+
+    @torch.no_grad()
     def step(self, closure=None, *, viewspace_grad=None, radii=None, xyz_gradient_accum=None, denom=None,
              max_radii2D=None):
         """One Adam update of every parameter that has a .grad (others are skipped, as in torch).
 
         Optional densification statistics of this step (all on the GPU): ``radii`` (N,) or (views,N) int32,
         ``viewspace_grad`` (N,3) or (views,N,3) = means2D.grad, and the (N,) or (N,1) float32 accumulators
-        to update in place.  They ride along in the same launch."""
+        to update in place.  They ride along in the same launch -- valid only when nothing resizes or resets
+        the accumulators between the backward and this step (no densify / prune on this iteration); otherwise
+        call update_densify_stats() where the reference updates them and step() without these arguments."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = _lib.load()
+        # checked first: a refused call must leave the step counters untouched
+        stats = None if radii is None else self._check_stats(viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D)
         buckets = {}     # (beta1, beta2, eps, step) -> list of (GsAdamGroup fields, keep-alive tensors)
         dev = None
         for group in self.param_groups:
@@ -98,27 +133,17 @@ class FusedAdam(torch.optim.Adam):
                 buckets.setdefault((float(beta1), float(beta2), float(group["eps"]), t), []).append(
                     ((p.data_ptr(), gk.data_ptr(), m.data_ptr(), v.data_ptr(), rows, stride, max(row_len, 1), lr),
                      (p, gk, m, v)))
-        stats = None
-        if radii is not None:
-            if not radii.is_cuda or radii.dtype != torch.int32:
-                raise RuntimeError("radii must be an int32 tensor on the GPU (the rasterizer's second output)")
-            radii = radii.contiguous()
-            views = 1 if radii.dim() == 1 else radii.shape[0]
-            n = radii.shape[-1]
-            if viewspace_grad is not None:
-                viewspace_grad = viewspace_grad.contiguous()
-                if viewspace_grad.numel() != views * n * 3 or viewspace_grad.dtype != torch.float32:
-                    raise ValueError("viewspace_grad must be float32 with shape (N,3) or (views,N,3) matching radii")
-            for name, t_ in (("xyz_gradient_accum", xyz_gradient_accum), ("denom", denom), ("max_radii2D", max_radii2D)):
-                if t_ is not None and (t_.numel() != n or t_.dtype != torch.float32 or not t_.is_contiguous()
-                                       or not t_.is_cuda):
-                    raise ValueError(f"{name} must be a contiguous float32 GPU tensor with N = {n} elements")
-            stats = (n, views, viewspace_grad, radii, xyz_gradient_accum, denom, max_radii2D)
+        if stats is not None:
             dev = dev or radii.device
         if dev is None:
             return loss
+        self._launch(buckets, stats, dev)
+        return loss
+
+    def _launch(self, buckets, stats, dev):
+        lib = _lib.load()
         calls = []
-        for key, items in buckets.items():
+        for key, items in (buckets.items() if buckets else []):
             for s in range(0, len(items), MAX_GROUPS):
                 calls.append((key, items[s:s + MAX_GROUPS]))
         if not calls:
@@ -138,4 +163,3 @@ class FusedAdam(torch.optim.Adam):
                     rc = lib.gs_adam_densify_step(len(items), arr, beta1, beta2, eps, t, 0, 0, None, None, None, None,
                                                   None, st)
                 _lib.check(rc, "gs_adam_densify_step")
-        return loss

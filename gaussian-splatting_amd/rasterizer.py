@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -244,7 +245,8 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
     # the rest stalls the GPU for ~0.1 ms per frame, so once a capacity is known from earlier frames
     # on this device the rest is launched against that capacity with D taken from device memory,
     # and D is checked afterwards (it arrived long before: the copy was queued right after the scan).
-    cap = _pair_capacity.get(dev.index, 0) if OPTIMISTIC_BINNING else 0
+    cap_key = (dev.index, tiles_x, tiles_y, row_b, row_e)
+    cap = _pair_capacity.get(cap_key) if OPTIMISTIC_BINNING else 0
     D = None
     out = None
     if cap > 0:
@@ -269,7 +271,7 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
         D = int(host_total.value)
     if out is None:
         out = bin_pairs(D, None)
-    _pair_capacity[dev.index] = max(_pair_capacity.get(dev.index, 0), D + D // 4 + 4096)
+    _pair_capacity.learn(cap_key, D)
     keys, point_list, ranges = out
     return BinningState(splat, radii, tiles_touched, order, offsets, D, keys[:D], point_list[:D], ranges)
 
@@ -277,17 +279,55 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
 # per-device state of the optimistic binning: pair capacity learnt from earlier frames, and a pinned
 # 4-byte slot + event for the asynchronous read-back of D
 OPTIMISTIC_BINNING = True
-_pair_capacity = {}
+
+
+class PairCapacityCache:
+    """Pair capacity learnt from earlier frames, per (device, tile grid, band of tile rows): two image sizes -- or two
+    threads rendering different cameras -- on one device do not overwrite each other's estimate (a capacity that is
+    too small costs a second binning pass, one that is too large only memory).  Guarded by a lock (SURVEY.md 8b:
+    the only mutable state of the host side is a per-device cache behind a mutex)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._cap = {}
+
+    def get(self, key) -> int:
+        with self._lock:
+            return self._cap.get(key, 0)
+
+    def learn(self, key, num_pairs: int) -> int:
+        with self._lock:
+            cap = max(self._cap.get(key, 0), num_pairs + num_pairs // 4 + 4096)
+            self._cap[key] = cap
+            return cap
+
+    def clear(self):
+        with self._lock:
+            self._cap.clear()
+
+    def snapshot(self) -> dict:
+        with self._lock:
+            return dict(self._cap)
+
+    def restore(self, snap: dict):
+        with self._lock:
+            self._cap = dict(snap)
+
+
+_pair_capacity = PairCapacityCache()
 _readback = {}
+_readback_lock = threading.Lock()
 
 
 def _readback_slot(dev):
-    """One pinned slot + event per (device, stream): frames queued on different streams do not share it."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    slot = _readback.get(key)
-    if slot is None:
-        slot = (torch.empty((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-        _readback[key] = slot
+    """One pinned slot + event per (device, stream, thread): frames queued on different streams or from different
+    threads do not share it."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
+    with _readback_lock:
+        slot = _readback.get(key)
+        if slot is None:
+            slot = (torch.empty((1,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+            _readback[key] = slot
     return slot
 
 

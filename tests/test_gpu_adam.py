@@ -151,3 +151,47 @@ def test_reference_state_surgery_and_errors(impl):
     c.grad = torch.randn(4, 3)
     with pytest.raises(RuntimeError):
         impl.FusedAdam([c], lr=1e-3).step()
+
+
+def test_densify_iteration_through_the_documented_recipe(impl):
+    """INTEGRATION.md section 7 on an iteration that densifies (train.py:185-217): the statistics are updated BEFORE
+    densify() resizes and zeroes the accumulators (update_densify_stats), the step afterwards takes no statistics and
+    skips the replaced parameters (their grad is None), and folding the old-N statistics into that step is refused."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    N = 4000
+    p = torch.nn.Parameter(torch.randn(N, 3, generator=g).to(dev))
+    other = torch.nn.Parameter(torch.randn(7, generator=g).to(dev))      # a parameter densify() does not replace
+    opt = impl.FusedAdam([{"params": [p], "lr": 1e-3, "name": "xyz"}, {"params": [other], "lr": 1e-2, "name": "x"}],
+                         lr=0.0, eps=1e-15)
+    p.grad, other.grad = torch.randn(N, 3, generator=g).to(dev), torch.randn(7, generator=g).to(dev)
+    opt.step()                                                            # some state to carry through the surgery
+    radii = torch.randint(0, 40, (N,), generator=g, dtype=torch.int32).to(dev)
+    vg = torch.randn(N, 3, generator=g).to(dev)
+    acc, den, mr = torch.zeros(N, 1, device=dev), torch.zeros(N, 1, device=dev), torch.zeros(N, device=dev)
+    p.grad, other.grad = torch.randn(N, 3, generator=g).to(dev), torch.randn(7, generator=g).to(dev)
+    # train.py:185-193
+    opt.update_densify_stats(viewspace_grad=vg, radii=radii, xyz_gradient_accum=acc, denom=den, max_radii2D=mr)
+    vis = radii > 0
+    assert torch.equal(mr, torch.where(vis, radii.float(), torch.zeros_like(mr)))
+    assert torch.equal(den.reshape(N), vis.float())
+    assert torch.allclose(acc.reshape(N), vg[:, :2].norm(dim=-1) * vis, rtol=1e-6, atol=0)
+    # train.py:203-208 -> scene/gaussian_model.py:476-530: prune by mask, optimizer state surgery, accumulators reset
+    mask = (acc.reshape(N) / den.reshape(N).clamp(min=1)) < 1.0
+    group = opt.param_groups[0]
+    st = opt.state.pop(group["params"][0])
+    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask].contiguous(), st["exp_avg_sq"][mask].contiguous()
+    q = torch.nn.Parameter(p.detach()[mask].contiguous().requires_grad_(True))
+    group["params"][0] = q
+    opt.state[q] = st
+    M = q.shape[0]
+    assert 0 < M < N
+    acc, den, mr = torch.zeros(M, 1, device=dev), torch.zeros(M, 1, device=dev), torch.zeros(M, device=dev)
+    # folding this iteration's (old-N) statistics into the step is refused with a message, not a crash
+    with pytest.raises(ValueError, match="densified or pruned"):
+        opt.step(viewspace_grad=vg, radii=radii, xyz_gradient_accum=acc, denom=den, max_radii2D=mr)
+    # train.py:217: the replaced parameter has no gradient and is skipped, the untouched one steps
+    before_q, before_other = q.detach().clone(), other.detach().clone()
+    opt.step()
+    assert torch.equal(q, before_q) and not torch.equal(other, before_other)
+    assert float(opt.state[q]["step"]) == 1 and float(opt.state[other]["step"]) == 2

@@ -275,19 +275,24 @@ def test_optimistic_binning_equals_exact_and_recovers_from_overflow(dgr):
     syn = importlib.import_module("gaussian-splatting_amd.synthetic")
     rz = importlib.import_module("gaussian-splatting_amd.rasterizer")
     dev = torch.device("cuda:0")
-    small = syn.make_scene(3000, 16, 96, 128, seed=11)
+    small = syn.make_scene(3000, 16, 203, 317, seed=11)     # same frame size: the capacity is kept per tile grid
     big = syn.make_scene(40000, 16, 203, 317, seed=12)
-    saved = dict(rz._pair_capacity)
+    other = syn.make_scene(3000, 16, 96, 128, seed=11)
+    key = (dev.index, (317 + 15) // 16, (203 + 15) // 16, 0, (203 + 15) // 16)
+    saved = rz._pair_capacity.snapshot()
     try:
         rz.OPTIMISTIC_BINNING = False
         exact = _bin_state(dgr, big, dev)
         rz.OPTIMISTIC_BINNING = True
         rz._pair_capacity.clear()
         _bin_state(dgr, small, dev)                     # learns a capacity far below the big frame's D
-        cap = rz._pair_capacity[dev.index]
-        assert cap < exact.num_pairs
+        cap = rz._pair_capacity.get(key)
+        assert 0 < cap < exact.num_pairs
         over = _bin_state(dgr, big, dev)                # overflows -> redone with the exact count
-        assert rz._pair_capacity[dev.index] >= exact.num_pairs
+        assert rz._pair_capacity.get(key) >= exact.num_pairs
+        learnt = rz._pair_capacity.get(key)
+        _bin_state(dgr, other, dev)                     # another frame size keeps its own estimate
+        assert rz._pair_capacity.get(key) == learnt and len(rz._pair_capacity.snapshot()) == 2
         opt = _bin_state(dgr, big, dev)                 # now runs optimistically within capacity
         for name, st in (("overflow", over), ("optimistic", opt)):
             assert st.num_pairs == exact.num_pairs, name
@@ -295,8 +300,7 @@ def test_optimistic_binning_equals_exact_and_recovers_from_overflow(dgr):
                 assert torch.equal(getattr(st, f), getattr(exact, f)), f"{name}: {f} differs"
     finally:
         rz.OPTIMISTIC_BINNING = True
-        rz._pair_capacity.clear()
-        rz._pair_capacity.update(saved)
+        rz._pair_capacity.restore(saved)
 
 
 @pytest.mark.parametrize("n,bits,use_count", [(0, 32, False), (1, 32, False), (5000, 32, False), (70000, 13, False),

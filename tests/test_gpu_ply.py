@@ -78,6 +78,30 @@ def test_shuffled_properties_and_extra_columns(ply_io, tmp_path):
             assert np.array_equal(want[k], m[k]), k   # so shuffling them permutes the columns, here as there
 
 
+@pytest.mark.parametrize("stride", [256, 512])
+def test_power_of_two_record_strides(ply_io, tmp_path, stride):
+    """Records of exactly 256 / 512 bytes (a degree-3 model plus extra float columns): the staging area of a
+    workgroup is sized to leave room for the kernel's static offset table inside the 64 KB of LDS."""
+    N, K = 1000, 16
+    m = make_model(N, K, seed=6)
+    base, names = ply_oracle.parse(ply_oracle.save_ply_bytes(**m))
+    extra = [f"extra_{i}" for i in range((stride - 4 * len(names)) // 4)]
+    fields = [(n, "<f4") for n in names + extra]
+    arr = np.zeros(N, dtype=np.dtype(fields))
+    assert arr.dtype.itemsize == stride
+    for n in names:
+        arr[n] = base[n]
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % N + \
+        "".join("property float %s\n" % n for n in names + extra) + "end_header\n"
+    data = header.encode() + arr.tobytes()
+    path = str(tmp_path / f"stride{stride}.ply")
+    open(path, "wb").write(data)
+    got = ply_io.load_ply(path, "cuda:0")
+    want = ply_oracle.load_ply_bytes(data)
+    for k in want:
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+
+
 def test_loaded_model_renders(ply_io, tmp_path):
     """End of the row: file -> device tensors -> the rasterizer, no host-side reshuffling in between."""
     impl = importlib.import_module("gaussian-splatting_amd")

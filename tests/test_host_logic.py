@@ -97,3 +97,28 @@ def test_default_t_eps_from_environment():
     env = dict(os.environ, GSPLAT_T_EPS="2")
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "GSPLAT_T_EPS" in out.stderr
+
+
+def test_pair_capacity_cache_is_per_device_and_tile_grid_and_thread_safe():
+    """SURVEY.md 8b "Threading": the one piece of mutable host state is a cache behind a lock; two image sizes (or
+    two bands) on one device keep separate capacities, so alternating cameras do not trigger re-binning."""
+    import threading
+    rz = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    c = rz.PairCapacityCache()
+    a, b = (0, 82, 53, 0, 53), (0, 50, 50, 0, 50)
+    assert c.get(a) == 0
+    assert c.learn(a, 7_535_647) >= 7_535_647
+    assert c.learn(b, 755_918) >= 755_918
+    assert c.get(a) >= 7_535_647 > c.get(b) >= 755_918          # the small frame did not shrink the large one's
+    assert c.learn(a, 10) == c.get(a) >= 7_535_647              # never shrinks
+    assert c.get((1,) + a[1:]) == 0 and c.get(a[:3] + (0, 7)) == 0   # other device / other band: nothing learnt
+
+    def worker(k):
+        for i in range(2000):
+            c.learn((0, k, k, 0, k), i)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(1, 9)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(c.get((0, k, k, 0, k)) == 1999 + 1999 // 4 + 4096 for k in range(1, 9))
+    assert isinstance(rz._pair_capacity, rz.PairCapacityCache)

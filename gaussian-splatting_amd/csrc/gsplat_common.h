@@ -17,12 +17,16 @@
 // reference's hard integer 3-sigma box (:393-399), half-open, clipped to the image.
 //
 // The backward per-Gaussian gradient rows are GS_GRAD_ROW = 16 floats = 64 bytes, one aligned 64-byte
-// segment per Gaussian.  The five geometric sums are accumulated as DOUBLES (bytes 0..39):
-//   d[0] d mean_x  d[1] d mean_y  d[2] d conic_a  d[3] d conic_b (each off-diagonal entry)  d[4] d conic_d
-// -- their chain rule through the 2x2 inverse cancels by orders of magnitude for large, nearly singular
-// splats, so the order in which the tiles' float atomics arrive used to move d means3D by ~1e-3 of its
-// value from run to run; fp64 atomics make the sums order-independent (bit-reproducible gradients) --
-// and the rest as floats (bytes 40..59): f[10] d opacity  f[11..13] d rgb  f[14] d depth  f[15] unused.
+// segment per Gaussian: six DOUBLES (bytes 0..47) and four floats (bytes 48..63).
+//   d[0..4] = sum over the Gaussian's pixels of pv * {dx, dy, dx^2, dx dy, dy^2},  d[5] = sum pv = d loss / d opacity
+// with pv = exp(power) * dL/dw and dx, dy measured from the CENTRE OF THE GAUSSIAN'S INTEGER BOX,
+// ((x_min + x_max - 1) >> 1, (y_min + y_max - 1) >> 1) -- not from its mean: the box centre is within half a box of
+// every pixel the Gaussian draws, so these sums stay small and exact-ish however far off screen the mean lies;
+// gs_preprocess_bwd moves them to the mean (q = opacity * pv, dx_mean = dx + (centre - mean)) in double, once per
+// Gaussian, and applies the conic factors.  fp64 atomics make the six sums independent of the order in which the
+// tiles arrive (bit-reproducible geometry gradients): their chain rule through the 2x2 inverse cancels by orders of
+// magnitude for large, nearly singular splats, where float sums in arrival order moved d means3D by ~1e-3 of its value
+// from run to run.   f[12..14] = d loss / d rgb,  f[15] = d loss / d depth  (float atomics).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

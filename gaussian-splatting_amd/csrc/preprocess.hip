@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, const float* __restrict__ means3D,
     const float* __restrict__ scales, const float* __restrict__ rots,
-    const float* __restrict__ cov6, const float* __restrict__ shs,
+    const float* __restrict__ cov6, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const int32_t* __restrict__ radii,
     const float4* __restrict__ grad_rows, float* __restrict__ g_means3D,
     float* __restrict__ g_means2D, float* __restrict__ g_scales, float* __restrict__ g_rots,
@@ -345,17 +345,36 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (drawn) {
         Geom g;
         if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
-        // row = 5 doubles (mean x, y, conic a, b, d) + floats 10..14 (opacity, r, g, b, depth): gsplat_common.h
+        // row = 6 doubles (moments of pv about the box centre) + floats 12..15 (rgb, depth): gsplat_common.h
         static_assert(GS_GRAD_ROW == 16, "row layout");
         const float4* row = grad_rows + (GS_GRAD_ROW / 4) * (size_t)i;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 r0 = PART != 2 ? row[0] : z4, r1 = PART != 2 ? row[1] : z4, r2 = row[2], r3 = row[3];
+        const float4 r0 = PART != 2 ? row[0] : z4, r1 = PART != 2 ? row[1] : z4, r2 = PART != 2 ? row[2] : z4, r3 = row[3];
         const auto dbl = [](float lo, float hi) {
-            return (float)__hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo));
+            return __hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo));
         };
-        const float d_mx = dbl(r0.x, r0.y), d_my = dbl(r0.z, r0.w), d_a = dbl(r1.x, r1.y), d_b = dbl(r1.z, r1.w);
-        const float d_d = dbl(r2.x, r2.y), d_op = r2.z, d_r = r2.w, d_g = r3.x;
-        const float d_bl = r3.y, d_z = r3.z;
+        float d_mx = 0.f, d_my = 0.f, d_a = 0.f, d_b = 0.f, d_d = 0.f, d_op = 0.f;
+        const float d_r = r3.x, d_g = r3.y, d_bl = r3.z, d_z = r3.w;
+        if (PART != 2) {
+            // moments of q = opacity * pv about the mean, from the moments of pv about the box centre (double: the
+            // shift can be thousands of pixels for a splat whose mean is far off screen)
+            const double op = (double)opacities[i];
+            const double M0 = dbl(r2.z, r2.w);
+            const double ex = (double)((g.xmin + g.xmax - 1) >> 1) - (double)g.mx;
+            const double ey = (double)((g.ymin + g.ymax - 1) >> 1) - (double)g.my;
+            const double S1x = dbl(r0.x, r0.y), S1y = dbl(r0.z, r0.w);
+            const double Sx = op * (ex * M0 + S1x), Sy = op * (ey * M0 + S1y);
+            const double Sxx = op * (ex * (ex * M0 + 2.0 * S1x) + dbl(r1.x, r1.y));
+            const double Sxy = op * (ex * (ey * M0 + S1y) + ey * S1x + dbl(r1.z, r1.w));
+            const double Syy = op * (ey * (ey * M0 + 2.0 * S1y) + dbl(r2.x, r2.y));
+            // power = -0.5 (a dx^2 + 2 b dx dy + d dy^2), dx = pixel - mean (reference :417-424)
+            d_mx = (float)((double)g.ca * Sx + (double)g.cb * Sy);
+            d_my = (float)((double)g.cd * Sy + (double)g.cb * Sx);
+            d_a = (float)(-0.5 * Sxx);
+            d_b = (float)(-0.5 * Sxy);
+            d_d = (float)(-0.5 * Syy);
+            d_op = (float)M0;
+        }
         gop = d_op;
         gm2[0] = d_mx;
         gm2[1] = d_my;
@@ -626,13 +645,13 @@ int launch_fwd(bool vec4, int N, int K, int H, int W, int row_b, int row_e, cons
 template <int DEG>
 int launch_bwd(int mode, int N, int K, int H, int W, const float* view, const float* proj,
                const float* campos, const float* means3D, const float* scales, const float* rots,
-               const float* cov6, const float* shs, const float* colors, const int32_t* radii,
+               const float* cov6, const float* opac, const float* shs, const float* colors, const int32_t* radii,
                const float4* rows, float* g_means3D, float* g_means2D, float* g_scales, float* g_rots,
                float* g_cov6, float* g_opac, float* g_shs, float* g_colors, bool acc, hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
 #define GS_LAUNCH_BWD(D_, MODE, PART)                                                                            \
     hipLaunchKernelGGL((preprocess_bwd_kernel<D_, MODE, PART>), grid, block, 0, stream, N, K, H, W, view, proj,     \
-                       campos, means3D, scales, rots, cov6, shs, colors, radii, rows, g_means3D, g_means2D,        \
+                       campos, means3D, scales, rots, cov6, opac, shs, colors, radii, rows, g_means3D, g_means2D,  \
                        g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors, acc)
     if (mode == 2) {
         GS_LAUNCH_BWD(0, 0, 1);
@@ -693,14 +712,14 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
 extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                                  const float* projmatrix, const float* campos, const float* means3D,
                                  const float* scales, const float* rotations, const float* cov3D_precomp,
-                                 const float* shs, const float* colors_precomp, const int32_t* radii,
-                                 const float* grad_rows, float* g_means3D, float* g_means2D,
+                                 const float* opacities, const float* shs, const float* colors_precomp,
+                                 const int32_t* radii, const float* grad_rows, float* g_means3D, float* g_means2D,
                                  float* g_scales, float* g_rotations, float* g_cov3D, float* g_opacities,
                                  float* g_shs, float* g_colors, int accumulate, void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
-    GS_REQUIRE(viewmatrix && projmatrix && campos && radii && grad_rows, "null argument");
+    GS_REQUIRE(viewmatrix && projmatrix && campos && opacities && radii && grad_rows, "null argument");
     GS_REQUIRE(((uintptr_t)grad_rows & 15) == 0, "grad_rows must be 16-byte aligned");
     GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
     GS_REQUIRE(!g_rotations || ((uintptr_t)g_rotations & 15) == 0, "g_rotations must be 16-byte aligned");
@@ -711,9 +730,9 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
     const int deg = shs ? sh_degree : 0;
     const float4* rows = (const float4*)grad_rows;
     switch (deg) {
-        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
-        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
-        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
-        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
     }
 }

@@ -30,19 +30,18 @@
 // per-lane box test is v_pk_max_u16 + v_pk_min_u16 + one compare, and a stopped lane is folded
 // into the same test by setting its packed pixel coordinate to 0xFFFFFFFF.
 //
-// Backward gradient accumulation: per Gaussian 10 partial sums (the mean/conic ones as raw
-// moments sum q dx, q dy, q dx^2, q dx dy, q dy^2 with q = dL/dpower; the per-Gaussian factors are
-// applied at flush time) are reduced over the 16 lanes of the row by a select-free DPP
-// reduce-scatter (22 adds, registers only); ten lanes of every row then store one dword each into
-// the 40-byte LDS slot of (4x4 block, list position) -- plain stores; after the batch the 16 lanes
-// of a DPP row take one pair each, lane b reads block b's slot, the same reduce-scatter adds the
-// 16 blocks up, and one row-shaped atomic per (tile, Gaussian) goes into that Gaussian's 64-byte
-// gradient row (the five geometric sums as fp64 atomics: gsplat_common.h).
+// Backward gradient accumulation: a visit reduces ONE value per lane, pv = G dL/dw, to its six moments in the
+// 4x4 block's own pixel coordinates (row_moments_and_totals: 8 DPP instructions) plus the totals of the four
+// colour / depth products (8 DPP adds) -- 16 half-rate instructions instead of the 22 a reduce-scatter of the ten
+// per-Gaussian sums needs, and the products with dx, dy are never formed.  Ten lanes of the row store one dword
+// each into the 40-byte LDS slot of (4x4 block, list position) -- plain stores; after the batch the 16 lanes of a
+// DPP row take one pair each, lane b reads block b's slot and moves its moments to the centre of the Gaussian's
+// box, a 22-add reduce-scatter adds the 16 blocks up, and one row-shaped atomic per (tile, Gaussian) goes into
+// that Gaussian's 64-byte gradient row (six geometric sums as fp64 atomics: gsplat_common.h).
 //
-// Bound: VALU issue (~21 instructions per visit forward, ~60 backward); HBM traffic is the record
+// Bound: VALU issue (~21 instructions per visit forward, ~50 backward); HBM traffic is the record
 // gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
 #include "gsplat_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -60,12 +59,6 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #endif
 #ifndef GS_BWD_BATCH_DEF
 #define GS_BWD_BATCH_DEF 32
-#endif
-#ifndef GS_BWD4_BATCH
-#define GS_BWD4_BATCH 32     // pairs per batch of the one-wave-per-tile backward
-#endif
-#ifndef GS_BWD4_CAP
-#define GS_BWD4_CAP 256      // (pair, block) slots per batch
 #endif
 constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch: 16 blocks x 32 slots x 40 B = 20 KB of LDS
 
@@ -151,14 +144,13 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
 template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
-                                              uint32_t* wl, uint16_t* posmap, f4* conic = nullptr) {
+                                              uint32_t* wl, uint16_t* posmap) {
     static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
     if (tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];
         const f4* p = splat + 3 * (size_t)id;
         f4 p0 = p[0], p1 = p[1], p2 = p[2];
-        if (conic) conic[tid] = f4{p0.z, p0.w, p1.x, 0.f};
         to_lds_form(p0, p1, p2);
         sq[3 * tid] = p0;
         sq[3 * tid + 1] = p1;
@@ -354,10 +346,91 @@ __device__ __forceinline__ float row_reduce_scatter10(const float (&v)[10], int 
     return t == 0 ? p0 : (t == 1 ? p1 : p2);
 }
 
-// gradient row (GS_GRAD_ROW = 16 floats = 64 bytes, see gsplat_common.h): sums 0..4 are doubles
-__device__ __forceinline__ void add_to_row(float* row, int idx, double v) {
-    if (idx < 5) atomicAdd(reinterpret_cast<double*>(row) + idx, v);
-    else atomicAdd(row + 5 + idx, (float)v);
+// gradient row (GS_GRAD_ROW = 16 floats = 64 bytes, see gsplat_common.h): sums 0..5 are doubles, 6..9 floats 12..15
+__device__ __forceinline__ void add_to_row(float* row, int idx, float v) {
+    if (idx < 6) atomicAdd(reinterpret_cast<double*>(row) + idx, (double)v);
+    else atomicAdd(row + 6 + idx, v);
+}
+
+// Per-visit reduction of a 4x4 block (one 16-lane DPP row, lane = 4 ly + lx) in LOCAL pixel coordinates:
+// from ONE value per lane, pv = G dL/dw, the six moments  M_ab = sum pv lx^a ly^b  (a + b <= 2), and beside them
+// the plain totals of up to four colour / depth products.  The moments about the Gaussian's mean that the gradient
+// needs follow per (block, Gaussian) at flush time from the block origin (dx = (bx - mean_x) + lx, q = opacity pv),
+// and M_00 is d/d opacity itself -- so a visit reduces 1 + 4 values instead of 10 products:
+//   level 1  x pairs      t  = pv[lx|1] + pv                               (odd lanes: 2 pv)          1 DPP add
+//   level 2  quad         u  = (M0, M1, M2) over lx in lanes lx = 0, 1, 2: constant 3x4 map          3 DPP mul/fmac
+//   level 3  y pairs      u += u[ly + 1] in even banks (odd banks keep their own)                     1 DPP add
+//   level 4  row          r  = (N0, N1, N2) over ly in banks 0, 1, 2: the same 3x4 map on banks      1 mul + 3 DPP fmac
+// Lane (bank B, lx X) of r holds M_XB: (0,0) M00, (1,0) M10, (2,0) M20, (0,1) M01, (1,1) M11, (0,2) M02.
+// Colours: two select-free halvings over the banks, then the quad sum -- every lane of bank j ends with the row
+// total of c_j (8 DPP adds, 7 without c3).  16 half-rate instructions per visit instead of 22, and the five
+// products q dx, q dy, q dx^2, q dx dy, q dy^2 are never formed.  k[] = this lane's seven map coefficients.
+struct MomentCoef { float a, b, c, d0, d1, d2, d3; };
+__device__ __forceinline__ MomentCoef moment_coef(int lane) {
+    const int x = lane & 3, y = (lane >> 2) & 3;
+    MomentCoef k;
+    k.a = x == 0 ? 1.0f : (x == 3 ? 0.0f : 0.5f);            // t[0,1,1,-]
+    k.b = x == 0 ? 1.0f : (x == 1 ? 2.0f : (x == 2 ? 4.0f : 0.0f));   // t[2]
+    k.c = x == 1 ? 0.5f : (x == 2 ? 2.5f : 0.0f);             // t[3]
+    k.d0 = y == 2 ? 4.0f : (y == 3 ? 0.0f : 1.0f);            // own bank
+    k.d1 = 1.0f;                                              // bank + 2 (written in banks 0, 1 only)
+    k.d2 = y == 1 ? 2.0f : 5.0f;                              // bank + 1 (written in banks 1, 2 only)
+    k.d3 = 1.0f;                                              // bank - 1 (written in bank 2 only)
+    return k;
+}
+
+template <bool HAS3>
+__device__ __forceinline__ void row_moments_and_totals(float pv, float c0, float c1, float c2, float c3,
+                                                       const MomentCoef& k, float& r, float& f) {
+    float t, u, e0, e1;
+    if (HAS3) {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %6, %6 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %2, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %3, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_mul_f32_dpp %1, %0, %11 quad_perm:[0,1,1,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %0, %12 quad_perm:[2,2,2,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %0, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %5, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %5, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_mul_f32 %4, %14, %1\n\t"
+            "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %4, %1, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_fmac_f32_dpp %4, %1, %16 row_shl:4 row_mask:0xf bank_mask:0x6\n\t"
+            "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %4, %1, %17 row_shr:4 row_mask:0xf bank_mask:0x4\n\t"
+            "s_nop 1"
+            : "=&v"(t), "=&v"(u), "=&v"(e0), "=&v"(e1), "=&v"(r), "=&v"(f)
+            : "v"(pv), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(k.a), "v"(k.b), "v"(k.c), "v"(k.d0), "v"(k.d1),
+              "v"(k.d2), "v"(k.d3));
+    } else {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %6, %6 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %2, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_mul_f32_dpp %1, %0, %11 quad_perm:[0,1,1,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %0, %12 quad_perm:[2,2,2,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %0, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %5, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %5, %3, %3 row_shr:4 row_mask:0xf bank_mask:0x2\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_mul_f32 %4, %14, %1\n\t"
+            "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0x7\n\t"
+            "v_fmac_f32_dpp %4, %1, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_fmac_f32_dpp %4, %1, %16 row_shl:4 row_mask:0xf bank_mask:0x6\n\t"
+            "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0x7\n\t"
+            "v_fmac_f32_dpp %4, %1, %17 row_shr:4 row_mask:0xf bank_mask:0x4\n\t"
+            "s_nop 1"
+            : "=&v"(t), "=&v"(u), "=&v"(e0), "=&v"(e1), "=&v"(r), "=&v"(f)
+            : "v"(pv), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(k.a), "v"(k.b), "v"(k.c), "v"(k.d0), "v"(k.d1),
+              "v"(k.d2), "v"(k.d3));
+    }
 }
 
 // HAS_ZA: an upstream gradient of the depth or alpha output exists (otherwise u has three terms and the depth sum is skipped)
@@ -376,7 +449,6 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     __shared__ uint32_t wl_all[NW][GS_ROWS * (BATCH + 1)];
     __shared__ uint16_t posmap_all[NW][GS_ROWS * BATCH];
     __shared__ float slots[(NBLK * BATCH + 1) * SLOT];   // plain stores, one 40-byte slot per row visit (+ a zero slot)
-    __shared__ f4 conic[BATCH];                      // unscaled (a, b, d) of every pair for the flush
     __shared__ uint64_t visited_all[NW];             // bit kk: the wave executed (did not skip) visit kk
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
@@ -406,15 +478,21 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     else if (t == 1) red_slot = ((bank & 1) ? 3 : 1) + 5 * (bank >> 1);
     else if (t == 2 && !(bank & 1) && (HAS_ZA || bank == 0)) red_slot = 4 + 5 * (bank >> 1);
     static_assert(BATCH <= 64 && BATCH % 16 == 0, "64-bit visited mask; the flush takes 16 pairs per round");
+    // what this lane stores per visit (row_moments_and_totals): slot = [M00 M10 M20 M01 M11 M02 | c0 c1 c2 c3]
+    int vis_slot = -1;
+    if (t == 3) vis_slot = (bank < 3 || HAS_ZA) ? 6 + bank : -1;
+    else if (bank == 0) vis_slot = t;
+    else if (bank == 1 && t < 2) vis_slot = 3 + t;
+    else if (bank == 2 && t == 0) vis_slot = 5;
+    const MomentCoef mk = moment_coef(lane);
     // this lane's float inside slot 0 of its row's block
-    float* my_slot = slots + (size_t)(wave * GS_ROWS + (lane >> 4)) * BATCH * SLOT + (red_slot < 0 ? 0 : red_slot);
+    float* my_slot = slots + (size_t)(wave * GS_ROWS + (lane >> 4)) * BATCH * SLOT + (vis_slot < 0 ? 0 : vis_slot);
     write_pad_record(sq, BATCH);
     if (tid < SLOT) slots[NBLK * BATCH * SLOT + tid] = 0.0f;
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
-        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
-                                               conic);
+        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave]);
         uint64_t visited = 0;
         uint32_t off_next = mylist[0];
         for (int kk = 0; kk < nmax; ++kk) {
@@ -442,40 +520,29 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             // goes on has 1 - w > 0, so the reciprocal needs no clamp.
             const float inv = stop ? 0.0f : __builtin_amdgcn_rcpf(1.0f - w);
             const float dLdw = T * u - rem * inv;
-            const float q = w * dLdw;          // dL/dpower
-            const f2 dxy = {dx, dy};
-            const f2 qxy = q * dxy;            // v_pk_mul_f32
-            const f2 qxd = qxy.x * dxy;
+            const float pv = G * dLdw;         // dL/dpower = opacity * pv: the opacity is applied at flush time
             const f2 c_rg = alpha * g_rg;
-            f2 c_bz;
-            if (HAS_ZA) c_bz = alpha * g_bz;
-            else c_bz = f2{alpha * g_bz.x, 0.0f};
-            float v[10];
-            v[0] = qxy.x;
-            v[1] = qxy.y;
-            v[2] = qxd.x;
-            v[3] = qxd.y;
-            v[4] = qxy.y * dy;
-            v[5] = G * dLdw;
-            v[6] = c_rg.x;
-            v[7] = c_rg.y;
-            v[8] = c_bz.x;
-            v[9] = c_bz.y;
+            const float c_b = alpha * g_bz.x, c_z = HAS_ZA ? alpha * g_bz.y : 0.0f;
             T = Tn;
             P = stop ? P_STOPPED : P;
-            const float red = row_reduce_scatter10<HAS_ZA>(v, t);
-            if (red_slot >= 0) my_slot[kk * SLOT] = red;   // one ds_write_b32 per visit, 10 lanes per row
+            float mom, tot;
+            row_moments_and_totals<HAS_ZA>(pv, c_rg.x, c_rg.y, c_b, c_z, mk, mom, tot);
+            if (vis_slot >= 0) my_slot[kk * SLOT] = t == 3 ? tot : mom;   // one ds_write_b32 per visit, 10 lanes per row
         }
         if (lane == 0) visited_all[wave] = visited;
         __syncthreads();
-        // flush: the 16 lanes of a DPP row take one pair, lane b the partial sums of 4x4 block b;
-        // the same row reduce-scatter adds the 16 blocks up.  Values 0..4 are the moments (sum q dx,
-        // q dy, q dx^2, q dx dy, q dy^2); the gradient row is
-        //   d mean = (a Sx + b Sy, d Sy + b Sx),  d conic = -0.5 (Sxx, Sxy, Syy).
+        // flush: the 16 lanes of a DPP row take one pair, lane b the sums of 4x4 block b (moved from the block's
+        // origin to the centre of the Gaussian's box); the 22-add row reduce-scatter adds the 16 blocks up and ten
+        // lanes add one value each to the Gaussian's row: sum pv {dx, dy, dx^2, dx dy, dy^2, 1} and the four
+        // colour / depth totals.  The conic and opacity factors are applied by gs_preprocess_bwd.
         const int blk = tid & 15;
         const uint64_t blk_visited = visited_all[blk >> 2];
         const uint16_t* blk_posmap = posmap_all[blk >> 2] + (blk & 3) * BATCH;
         const float* blk_slots = slots + (size_t)blk * BATCH * SLOT;
+        // origin of 4x4 block blk = 4 wave + row (make_ctx)
+        const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
+        const float blk_x = (float)(tile_x0 + ((blk >> 2) & 1) * GS_SUB + (blk & 1) * GS_QUAD);
+        const float blk_y = (float)(tile_y0 + (blk >> 3) * GS_SUB + ((blk >> 1) & 1) * GS_QUAD);
 #pragma unroll
         for (int r = 0; r < BATCH / 16; ++r) {
             const int j = r * 16 + (tid >> 4);
@@ -486,328 +553,38 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const bool any = ((vm >> (lane & 48)) & 0xFFFFull) != 0;
             // lanes without a slot read the always-zero slot behind the last one
             const float* sl = valid ? blk_slots + pos * SLOT : slots + NBLK * BATCH * SLOT;
-            float v[10];
+            float m[10];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) v[k] = sl[k];
+            for (int k = 0; k < 10; ++k) m[k] = sl[k];
+            // block b's local moments -> moments of pv about the CENTRE OF THE GAUSSIAN'S BOX (an integer pixel that
+            // every tile derives identically): dx_o = (block origin - centre) + lx with small exact integers, so
+            // nothing is lost here however far away the mean is; gs_preprocess_bwd moves the sums to the mean, in
+            // double, once per Gaussian
+            const f4 r1 = sq[3 * j + 1];
+            const uint32_t blo = __float_as_uint(r1.z), bhi = __float_as_uint(r1.w);
+            const float ex = blk_x - (float)(((blo & 0xFFFFu) + (bhi & 0xFFFFu)) >> 1);
+            const float ey = blk_y - (float)(((blo >> 16) + (bhi >> 16)) >> 1);
+            const float exM = ex * m[0], eyM = ey * m[0];
+            float v[10];
+            v[0] = exM + m[1];
+            v[1] = eyM + m[3];
+            v[2] = __builtin_fmaf(ex, exM + 2.0f * m[1], m[2]);
+            v[3] = __builtin_fmaf(ex, eyM + m[3], m[4]) + ey * m[1];
+            v[4] = __builtin_fmaf(ey, eyM + 2.0f * m[3], m[5]);
+            v[5] = m[0];
+            v[6] = m[6];
+            v[7] = m[7];
+            v[8] = m[8];
+            v[9] = m[9];
             const float sum = row_reduce_scatter10<HAS_ZA>(v, t);
-            const float other = __shfl_xor(sum, 1);
             if (any && red_slot >= 0) {
-                float outv = sum;
-                if (red_slot < 2) {
-                    const f4 cn = conic[j];           // (a, b, d) as preprocess wrote them
-                    outv = (red_slot == 0 ? cn.x : cn.z) * sum + cn.y * other;
-                } else if (red_slot < 5) {
-                    outv = -0.5f * sum;
-                }
+                const float outv = sum;
                 add_to_row(grad_rows + (size_t)sid[j] * GS_GRAD_ROW, red_slot, outv);
             }
         }
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Backward, second form: ONE wave64 per 16x16 tile, FOUR pixels per lane.
-//
-// Why: the first form (lane = pixel, 16 lanes per 4x4 block) spends 22 of its 59 instructions per visit
-// on the 16-lane reduce-scatter, and those DPP adds issue at half rate.  Here a 4x4 block is 4 lanes
-// (lane = one 4x1 pixel strip); the four lanes of a block sit in the four banks of a DPP row (lanes
-// q, q+4, q+8, q+12), so the whole cross-lane reduction is the two select-free halving steps (row_ror:8,
-// row_shl/shr:4 with bank masks): 16 DPP adds per 256 pixel-slots instead of 22 per 64.  The four
-// pixels of a lane are added up with plain full-rate VALU first, and share dy, C' dy and the record.
-// A wave now walks SIXTEEN hit lists (one per block) in lockstep.
-//
-// LDS per wave (= per workgroup): records, the 16 lists (entry = record offset | slot offset << 16),
-// and a COMPACT slot array: one 48-byte slot per (pair, block it overlaps), allocated by a prefix sum
-// over the batch -- ~6 slots per pair on the benchmark scene instead of 16 -- capped at CAP slots: a
-// batch is cut short when its pairs need more.  The flush adds a pair's slots (contiguous) in double
-// and issues one row-shaped atomic per (tile, Gaussian).  No __syncthreads anywhere.
-// ---------------------------------------------------------------------------------------------
-
-
-// First two steps of row_reduce_scatter10: halves 10 values over lane^8 and lane^4.  Lane with bank
-// b = (lane >> 2) & 3 ends with the totals over {lane, lane^4, lane^8, lane^12} of
-//   p0 = v[(b&1 ? 2 : 0) + 5 (b>>1)]   p1 = v[(b&1 ? 3 : 1) + 5 (b>>1)]   p2 = v[4 + 5 (b>>1)]
-__device__ __forceinline__ void bank_reduce_scatter10(const float (&v)[10], float& p0, float& p1, float& p2) {
-    float o0, o1, o2, o3, o4;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %3, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %5, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %6, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %5, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %6, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %7, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %7, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1"
-        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(p0), "=&v"(p1), "=&v"(p2)
-        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
-          "v"(v[9]));
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-#ifdef GS_BWD4_STATS
-__device__ unsigned long long g_bwd4_stats[8];   // batches, wave-visits, block-visits with a live lane, sum n_eff, sum nslots, flush iterations, live lane-pixels
-#define B4_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bwd4_stats[i], (unsigned long long)(v)); } while (0)
-#else
-#define B4_STAT(i, v) do { } while (0)
-#endif
-
-template <int BATCH, int CAP, bool HAS_ZA>
-__global__ __launch_bounds__(64) void render_bwd4_kernel(
-    int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
-    const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
-    const float* __restrict__ g_depth, const float* __restrict__ g_alpha, float* __restrict__ grad_rows,
-    float t_eps) {
-    static_assert(BATCH >= 16 && BATCH <= 64 && BATCH % 4 == 0, "one staging lane per pair");
-    static_assert(CAP >= 16 && 48 * (CAP + 1) < 65536 && 48 * (BATCH + 1) < 65536, "list entries are two 16-bit byte offsets");
-    constexpr int NBLK = 16;            // 4x4-pixel blocks per tile, one hit list each
-    constexpr int LSTR = BATCH + 1;     // list stride (odd: the 16 lists start in different banks; +1 for the prefetch)
-    constexpr int SLOTF = 12;           // floats per slot: 4 lanes x (p0, p1, p2)
-    constexpr uint32_t PAD_ENTRY = 48u * BATCH | (48u * CAP) << 16;   // pad record, dump slot
-    __shared__ f4 sq[3 * (BATCH + 1)];
-    __shared__ f4 conic[BATCH];
-    __shared__ uint32_t sid[BATCH];
-    __shared__ __align__(16) uint32_t lists[(NBLK * LSTR + 3) / 4 * 4];
-    __shared__ uint32_t hit_off[BATCH + 1];
-    __shared__ __align__(16) float slots[(CAP + 1) * SLOTF];
-    const int lane = threadIdx.x;
-    const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
-    const int tx0 = (tile % tiles_x) * GS_TILE, ty0 = (tile / tiles_x) * GS_TILE;
-    // lane -> block (brow, bcol) of the 4x4 grid of blocks, strip k of the block: pixels (x0 .. x0+3, y)
-    const int brow = lane >> 4, bcol = lane & 3, k = (lane >> 2) & 3;
-    const int y = ty0 + 4 * brow + k, x0 = tx0 + 4 * bcol;
-    const uint32_t* mylist = lists + (brow * 4 + bcol) * LSTR;
-    const uint2 range = ranges[tile];
-    const float fy = (float)y;
-    float fx[4], gr[4], gg[4], gb[4], gz[4], ga[4], A[4], T[4], rem[4];
-    uint32_t P[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int x = x0 + e;
-        const bool inside = x < W && y < H;
-        fx[e] = (float)x;
-        gr[e] = gg[e] = gb[e] = gz[e] = ga[e] = 0.f;
-        A[e] = 0.f;
-        T[e] = 1.f;
-        rem[e] = 0.f;
-        P[e] = inside ? ((uint32_t)x | (uint32_t)y << 16) : P_STOPPED;
-        if (inside) {
-            const size_t HW = (size_t)H * W, p = (size_t)y * W + x;
-            gr[e] = g_img[p];
-            gg[e] = g_img[HW + p];
-            gb[e] = g_img[2 * HW + p];
-            if (g_depth) gz[e] = g_depth[p];
-            if (g_alpha) ga[e] = g_alpha[p];
-            rem[e] = (gr[e] * aux_rgb[p] + gg[e] * aux_rgb[HW + p] + gb[e] * aux_rgb[2 * HW + p]) + gz[e] * out_depth[p] +
-                     ga[e] * out_alpha[p];
-        }
-    }
-    // which sum of the gradient row this lane owns in the flush (16 lanes per pair, lane c reads float c
-    // of the pair's slots: c = 3 * bank + i holds p_i of bank_reduce_scatter10); -1: nothing
-    //   c: 0 Sx  1 Sy  2 Syy  3 Sxx  4 Sxy  5 (dup)  6 opacity  7 red  8 depth  9 green  10 blue  11 (dup)
-    const int fc = lane & 15;
-    int oidx = -1;
-    {
-        constexpr int map[16] = {0, 1, 4, 2, 3, -1, 5, 6, 9, 7, 8, -1, -1, -1, -1, -1};
-        oidx = map[fc];
-    }
-    if (lane == 0) {
-        const f4 z = {0.f, 0.f, 0.f, 0.f};
-        sq[3 * BATCH] = z;
-        sq[3 * BATCH + 1] = f4{0.f, 0.f, __uint_as_float(PAD_LO), __uint_as_float(PAD_HI)};
-        sq[3 * BATCH + 2] = z;
-    }
-    const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t n_eff = 0;
-    for (uint32_t base = range.x; base < range.y; base += n_eff) {
-        const bool done = (P[0] & P[1] & P[2] & P[3]) == P_STOPPED;
-        if (__all(done)) break;
-        const int n = min((int)(range.y - base), BATCH);
-        // ---- stage the records, find the blocks every pair overlaps
-        uint32_t hm = 0;
-        if (lane < n) {
-            const uint32_t id = point_list[base + lane];
-            const f4* p = (const f4*)splat + 3 * (size_t)id;
-            f4 p0 = p[0], p1 = p[1], p2 = p[2];
-            conic[lane] = f4{p0.z, p0.w, p1.x, 0.f};
-            const uint32_t rx = __float_as_uint(p1.w), ry = __float_as_uint(p2.w);
-            to_lds_form(p0, p1, p2);
-            sq[3 * lane] = p0;
-            sq[3 * lane + 1] = p1;
-            sq[3 * lane + 2] = p2;
-            sid[lane] = id;
-            const int xa = max((int)(rx & 0xFFFF), tx0) - tx0, xb = min((int)(rx >> 16) - 1, tx0 + GS_TILE - 1) - tx0;
-            const int ya = max((int)(ry & 0xFFFF), ty0) - ty0, yb = min((int)(ry >> 16) - 1, ty0 + GS_TILE - 1) - ty0;
-            if (xa <= xb && ya <= yb) {
-                const uint32_t cm = (2u << (xb >> 2)) - (1u << (xa >> 2));
-                const uint32_t rm = (2u << (yb >> 2)) - (1u << (ya >> 2));
-                hm = cm * ((rm & 1u) | (rm & 2u) << 3 | (rm & 4u) << 6 | (rm & 8u) << 9);
-            }
-        }
-        // blocks whose 16 pixels have all stopped take no more pairs (their lanes: q, q+4, q+8, q+12 of a row)
-        {
-            const uint64_t dm = __ballot((P[0] & P[1] & P[2] & P[3]) == P_STOPPED);
-            const uint64_t all4 = dm & (dm >> 4) & (dm >> 8) & (dm >> 12);       // bit 16 r + q: block (r, q) is done
-            const uint32_t done = (uint32_t)(all4 & 0xFull) | (uint32_t)((all4 >> 16) & 0xFull) << 4 |
-                                  (uint32_t)((all4 >> 32) & 0xFull) << 8 | (uint32_t)((all4 >> 48) & 0xFull) << 12;
-            hm &= ~done;
-        }
-        const uint32_t cnt = __popc(hm);
-        const uint32_t incl = wave_incl_scan_u32(cnt, lane);
-        n_eff = __popcll(__ballot(lane < n && incl <= (uint32_t)CAP));     // >= 1: a pair has at most 16 slots
-        if (lane >= (int)n_eff) hm = 0;
-        const uint32_t excl = incl - cnt;
-        if (lane < (int)n_eff) hit_off[lane] = excl;
-        if (lane == (int)n_eff - 1) hit_off[n_eff] = incl;
-        const uint32_t nslots = __builtin_amdgcn_readlane(incl, n_eff - 1);   // may be 0: every block the batch touches is done
-        // ---- lists: everything is a pad entry first, then the hits in list order
-        {
-            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            const u4 padv = {PAD_ENTRY, PAD_ENTRY, PAD_ENTRY, PAD_ENTRY};
-            u4* l4 = (u4*)lists;
-            for (int i = lane; i < (NBLK * LSTR + 3) / 4; i += 64) l4[i] = padv;
-            const f4 z = {0.f, 0.f, 0.f, 0.f};
-            f4* s4 = (f4*)slots;
-            for (int i = lane; i < (int)nslots * 3; i += 64) s4[i] = z;    // a block that stops early leaves zeros
-        }
-        int nmax = 0;
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            const bool hit = (hm >> b) & 1u;
-            const uint64_t m = __ballot(hit);
-            if (hit) {
-                const uint32_t slot = excl + __popc(hm & ((1u << b) - 1u));
-                lists[b * LSTR + __popcll(m & lt)] = 48u * (uint32_t)lane | (48u * slot) << 16;
-            }
-            nmax = max(nmax, (int)__popcll(m));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        B4_STAT(0, 1); B4_STAT(3, n_eff); B4_STAT(4, nslots);
-        // ---- visits
-        // list entry two visits ahead, record one visit ahead: the only LDS latency left in the loop is hidden
-        uint32_t e_cur = mylist[0], e_next = mylist[nmax > 1 ? 1 : 0];
-        Rec rec_next = load_rec(sq, e_cur & 0xFFFFu);
-        for (int kk = 0; kk < nmax; ++kk) {
-            if ((kk & 7) == 0 && __all((P[0] & P[1] & P[2] & P[3]) == P_STOPPED)) break;
-            const uint32_t entry = e_cur;
-            const Rec rec = rec_next;
-            e_cur = e_next;
-            rec_next = load_rec(sq, e_cur & 0xFFFFu);        // entries past the list are pad entries (lists are pre-filled)
-            e_next = mylist[kk + 2 <= BATCH ? kk + 2 : BATCH];
-            const uint32_t lo = __float_as_uint(rec.q1.z), hi = __float_as_uint(rec.q1.w);
-            const float dy = fy - rec.q0.y;
-            const float bdy = rec.q0.w, cdy = rec.q1.x * dy;
-            float q[4], pv[4], al[4], dx[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool act = in_box(P[e], lo, hi);
-                dx[e] = fx[e] - rec.q0.x;
-                const float t = __builtin_fmaf(bdy, dy, rec.q0.z * dx[e]);          // same rounding as gauss_power2
-                const float power2 = __builtin_fmaf(cdy, dy, t * dx[e]);
-                const float G = act ? __builtin_amdgcn_exp2f(power2) : 0.0f;
-                const float w = G * rec.q1.y;
-                const float alpha = w * T[e];
-                const float u = HAS_ZA ? __builtin_fmaf(rec.q2.x, gr[e], __builtin_fmaf(rec.q2.y, gg[e],
-                                             __builtin_fmaf(rec.q2.z, gb[e], __builtin_fmaf(rec.q2.w, gz[e], ga[e]))))
-                                       : __builtin_fmaf(rec.q2.x, gr[e], __builtin_fmaf(rec.q2.y, gg[e], rec.q2.z * gb[e]));
-                A[e] += alpha;
-                const float Tn = 1.0f - A[e];
-                const bool stop = Tn <= t_eps;
-                rem[e] = __builtin_fmaf(-u, alpha, rem[e]);      // total - sum_{j<=i} u_j alpha_j
-                // Behind a pixel that stops here nothing is composited (every later alpha is 0, exactly so for
-                // t_eps = 0), so the tail term is 0 by definition -- not the rounding residue of total - prefix.
-                // A pixel that goes on has 1 - w > 0, so the reciprocal needs no clamp.
-                const float inv = stop ? 0.0f : __builtin_amdgcn_rcpf(1.0f - w);
-                const float dLdw = T[e] * u - rem[e] * inv;
-                pv[e] = G * dLdw;
-                q[e] = w * dLdw;
-                al[e] = alpha;
-                T[e] = Tn;
-                P[e] = stop ? P_STOPPED : P[e];
-            }
-#ifdef GS_BWD4_STATS
-            {
-                B4_STAT(1, 1);
-                const bool live = (entry & 0xFFFFu) != 48u * BATCH && (P[0] & P[1] & P[2] & P[3]) != P_STOPPED;
-                const unsigned long long lm = __ballot(live);
-                unsigned nb = 0;
-                for (int b = 0; b < 16; ++b) nb += ((lm >> ((b >> 2) * 16 + (b & 3))) & 0x1111ull) != 0;
-                B4_STAT(2, nb);
-                const unsigned long long a4 = __popcll(__ballot(al[0] != 0.f)) + __popcll(__ballot(al[1] != 0.f)) + __popcll(__ballot(al[2] != 0.f)) + __popcll(__ballot(al[3] != 0.f));
-                B4_STAT(6, a4);
-            }
-#endif
-            float v[10];
-            const float m0 = q[0] * dx[0], m1 = q[1] * dx[1], m2 = q[2] * dx[2], m3 = q[3] * dx[3];
-            const float sq_ = (q[0] + q[1]) + (q[2] + q[3]);
-            v[0] = (m0 + m1) + (m2 + m3);
-            v[1] = sq_ * dy;
-            v[2] = __builtin_fmaf(m0, dx[0], m1 * dx[1]) + __builtin_fmaf(m2, dx[2], m3 * dx[3]);
-            v[3] = v[0] * dy;
-            v[4] = v[1] * dy;
-            v[5] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
-            v[6] = __builtin_fmaf(al[0], gr[0], al[1] * gr[1]) + __builtin_fmaf(al[2], gr[2], al[3] * gr[3]);
-            v[7] = __builtin_fmaf(al[0], gg[0], al[1] * gg[1]) + __builtin_fmaf(al[2], gg[2], al[3] * gg[3]);
-            v[8] = __builtin_fmaf(al[0], gb[0], al[1] * gb[1]) + __builtin_fmaf(al[2], gb[2], al[3] * gb[3]);
-            v[9] = HAS_ZA ? __builtin_fmaf(al[0], gz[0], al[1] * gz[1]) + __builtin_fmaf(al[2], gz[2], al[3] * gz[3]) : 0.0f;
-            float p0, p1, p2;
-            bank_reduce_scatter10(v, p0, p1, p2);
-            float* sl = (float*)((char*)slots + (entry >> 16)) + 3 * k;
-            sl[0] = p0;
-            sl[1] = p1;
-            sl[2] = p2;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- flush: 16 lanes per pair, lane c adds float c of the pair's slots (contiguous), in double
-        for (int jb = 0; jb < (int)n_eff; jb += 4) {
-            const int j = jb + (lane >> 4);
-            const bool have = j < (int)n_eff;
-            const uint32_t s0 = have ? hit_off[j] : 0u, s1 = have ? hit_off[j + 1] : 0u;
-            const int cj = (int)(s1 - s0);
-            const int maxc = max(max(__builtin_amdgcn_readlane(cj, 0), __builtin_amdgcn_readlane(cj, 16)),
-                                 max(__builtin_amdgcn_readlane(cj, 32), __builtin_amdgcn_readlane(cj, 48)));
-            const float* sl = slots + (size_t)s0 * SLOTF + (fc < SLOTF ? fc : 0);
-            double acc = 0.0;
-            B4_STAT(5, maxc);
-            for (int i = 0; i < maxc; ++i)
-                if (i < cj) acc += (double)sl[i * SLOTF];
-            const double other = __shfl_xor(acc, 1);
-            if (have && oidx >= 0) {
-                double outv = acc;
-                if (oidx < 2) {
-                    const f4 cn = conic[j];           // (a, b, d) as preprocess wrote them
-                    outv = (double)(oidx == 0 ? cn.x : cn.z) * acc + (double)cn.y * other;
-                } else if (oidx < 5) {
-                    outv = -0.5 * acc;
-                }
-                add_to_row(grad_rows + (size_t)sid[j] * GS_GRAD_ROW, oidx, outv);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 }  // namespace
 
@@ -856,34 +633,14 @@ extern "C" int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ra
     if (tile_row_begin >= tile_row_end) return GS_OK;
     const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
     GS_REQUIRE(((uintptr_t)grad_rows & 15) == 0, "grad_rows must be 16-byte aligned");
-    static const int form = [] { const char* e = getenv("GSPLAT_BWD_FORM"); return e ? atoi(e) : 1; }();
-    if (form == 1 && (g_depth || g_alpha))      // first form: lane = pixel, 4 waves per tile
+    if (g_depth || g_alpha)
         hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, true>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
                            (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
                            g_image, g_depth, g_alpha, grad_rows, t_eps);
-    else if (form == 1)
-        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, false>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
-                           (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
-                           g_image, g_depth, g_alpha, grad_rows, t_eps);
-    else if (g_depth || g_alpha)
-        hipLaunchKernelGGL((render_bwd4_kernel<GS_BWD4_BATCH, GS_BWD4_CAP, true>), dim3(ntiles), dim3(64), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
-                           (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
-                           g_image, g_depth, g_alpha, grad_rows, t_eps);
     else
-        hipLaunchKernelGGL((render_bwd4_kernel<GS_BWD4_BATCH, GS_BWD4_CAP, false>), dim3(ntiles), dim3(64), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, false>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
                            (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
                            g_image, g_depth, g_alpha, grad_rows, t_eps);
     GS_CHECK_LAUNCH("render_bwd");
     return GS_OK;
 }
-
-#ifdef GS_BWD4_STATS
-extern "C" int gs_debug_bwd4_stats(unsigned long long* host8, int reset) {
-    GS_CHECK_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_bwd4_stats), 8 * sizeof(unsigned long long)));
-    if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        GS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd4_stats), z, sizeof(z)));
-    }
-    return GS_OK;
-}
-#endif

@@ -288,8 +288,8 @@ class _RasterizeSharded(torch.autograd.Function):
                     with _stage("exchange_bwd_wait"):
                         _wait(w_rows)
                     w_rows = None
-                g = R.preprocess_backward(views[v], means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
-                                          radii[v], rows[off:off + n] if v == rank else rows_mine[v], needs,
+                g = R.preprocess_backward(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                          colors_precomp, radii[v], rows[off:off + n] if v == rank else rows_mine[v], needs,
                                           (n, 3) if per_view_means2D else None, accumulate_into=acc)
                 if per_view_means2D and needs[1]:
                     g_m2d[v] = g[1]
@@ -468,7 +468,7 @@ class _RasterizeReplicated(torch.autograd.Function):
                 with _stage("preprocess_bwd"):
                     R._lib.check(lib.gs_preprocess_bwd(
                         e - b, K, settings.sh_degree, H, W, *cam_p, at(means3D, b), at(scales, b), at(rotations, b),
-                        at(cov3D_precomp, b), at(shs, b), at(colors_precomp, b), at(radii, b), at(rows, b),
+                        at(cov3D_precomp, b), at(opacities, b), at(shs, b), at(colors_precomp, b), at(radii, b), at(rows, b),
                         at(g_m3, b), at(g_m2, b), at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b), at(g_sh, b),
                         at(g_col, b), 0, st), "gs_preprocess_bwd")
                 if reduce_now:      # queued behind this range's launches on RCCL's stream; the next range's kernels overlap it

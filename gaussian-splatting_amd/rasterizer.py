@@ -379,8 +379,8 @@ def render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_im
     return rows
 
 
-def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, radii, rows,
-                        needs, means2D_shape, accumulate_into=None, out=None):
+def preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp, radii,
+                        rows, needs, means2D_shape, accumulate_into=None, out=None):
     """gs_preprocess_bwd on the current stream.  `needs` = 8 flags in the order of GaussianRasterizer.forward's
     arguments; returns the 8 gradients (None where not needed).  accumulate_into = the 8-tuple a previous
     call returned: this view's gradients are added into those tensors (means2D's, per view, is fresh).
@@ -417,7 +417,7 @@ def preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs
     with _stage("preprocess_bwd"):
         _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
-                                         _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
+                                         _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
                                          _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
                                          _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors),
                                          0 if accumulate_into is None else 1, _stream()),
@@ -471,8 +471,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             rows, ctx.rows = ctx.rows, None          # cleared by the forward; a second backward clears its own
             rows = render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_image, g_depth, g_alpha,
                                    rows, ctx.t_eps, ctx.band)
-            grads = preprocess_backward(settings, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp,
-                                        radii, rows, ctx.needs_input_grad, ctx.means2D_shape)
+            grads = preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                        colors_precomp, radii, rows, ctx.needs_input_grad, ctx.means2D_shape)
         return (*grads, None, None, None, None)
 
 

@@ -137,10 +137,12 @@ int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32
 /*
  * Backward of gs_render_fwd (the reference gets it from torch autograd).  g_image (3,H,W),
  * g_depth / g_alpha (H,W) optional.  grad_rows (N rows of gs_grad_row_floats() = 16 floats = 64 bytes, 16-byte
- * aligned) must be zero on entry and receives, per Gaussian, five DOUBLES (bytes 0..39): d/d screen mean x, y
- * (pixels), d/d conic a, d/d each off-diagonal conic entry, d/d conic d -- fp64 atomics, so these sums do not
- * depend on the order in which the tiles arrive -- and five floats (bytes 40..59): d/d opacity, d/d rgb, d/d depth.
- * The rows are an opaque hand-over to gs_preprocess_bwd.  t_eps must equal the forward's.
+ * aligned) must be zero on entry and receives, per Gaussian, six DOUBLES (bytes 0..47): the sums over its pixels
+ * of pv {dx, dy, dx^2, dx dy, dy^2, 1} with pv = exp(power) dL/dw and dx, dy measured from the centre of its
+ * integer box (csrc/gsplat_common.h) -- fp64 atomics, so they do not depend on the order in which the tiles
+ * arrive -- and four floats (bytes 48..63): d/d rgb, d/d depth.  The rows are an opaque hand-over to
+ * gs_preprocess_bwd, which turns the moments into d/d screen mean, d/d conic and d/d opacity.
+ * t_eps must equal the forward's.
  */
 int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const uint32_t* point_list,
                   const float* aux_rgb, const float* out_depth, const float* out_alpha,
@@ -163,7 +165,7 @@ int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const
 int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                       const float* projmatrix, const float* campos, const float* means3D,
                       const float* scales, const float* rotations, const float* cov3D_precomp,
-                      const float* shs, const float* colors_precomp, const int32_t* radii,
+                      const float* opacities, const float* shs, const float* colors_precomp, const int32_t* radii,
                       const float* grad_rows, float* g_means3D, float* g_means2D, float* g_scales,
                       float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
                       float* g_colors_precomp, int accumulate, void* stream);

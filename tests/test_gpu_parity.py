@@ -487,18 +487,21 @@ def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
         S = Rm @ Rm.transpose(1, 2) + 1e-4 * torch.eye(3)
         cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous().to(dev)
         sh = s = q = None
-    rows = torch.randn(N, 16, generator=torch.Generator().manual_seed(2)).to(dev)
+    gr = torch.Generator().manual_seed(2)      # rows: six doubles + four floats (csrc/gsplat_common.h)
+    rows = torch.cat([torch.randn(N, 6, generator=gr, dtype=torch.float64).view(torch.float32),
+                      torch.randn(N, 4, generator=gr)], dim=1).contiguous().to(dev)
+    assert rows.shape == (N, R.grad_row_floats())
     needs = [True] * 8
     per_view, radii = [], []
     for v in views:
         st = _scene_settings(dgr, v, dev)
         _, r, *_ = R.preprocess(st, m3, op, s, q, cov6, sh, colors)
         radii.append(r)
-        per_view.append(R.preprocess_backward(st, m3, s, q, cov6, sh, colors, r, rows, needs, (N, 3)))
+        per_view.append(R.preprocess_backward(st, m3, op, s, q, cov6, sh, colors, r, rows, needs, (N, 3)))
     assert int(((radii[0] > 0) != (radii[1] > 0)).sum()) > 0      # some Gaussians are drawn in one view only
     acc = None
     for v, r in zip(views, radii):
-        acc = R.preprocess_backward(_scene_settings(dgr, v, dev), m3, s, q, cov6, sh, colors, r, rows, needs, (N, 3),
+        acc = R.preprocess_backward(_scene_settings(dgr, v, dev), m3, op, s, q, cov6, sh, colors, r, rows, needs, (N, 3),
                                     accumulate_into=acc)
     torch.cuda.synchronize()
     names = ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "cov3D")

@@ -28,7 +28,7 @@ for world in (1, 2, 4, 8):
     n = N // world
     views = [settings(syn.jitter_view(sc, v)) for v in range(world)]
     m3, sh, op, s, q = (getattr(sc, k)[:n].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
-    rows = torch.randn(world, n, 16, device=dev)
+    rows = torch.cat([torch.randn(world, n, 6, dtype=torch.float64).view(torch.float32), torch.randn(world, n, 4)], dim=2).contiguous().to(dev)
     needs = [True] * 8
 
     def step():
@@ -38,7 +38,7 @@ for world in (1, 2, 4, 8):
             radii.append(r)
         acc = None
         for v in range(world):
-            acc = R.preprocess_backward(views[v], m3, s, q, None, sh, None, radii[v], rows[v], needs, (n, 3),
+            acc = R.preprocess_backward(views[v], m3, op, s, q, None, sh, None, radii[v], rows[v], needs, (n, 3),
                                         accumulate_into=acc)
         return acc
 

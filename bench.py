@@ -617,7 +617,28 @@ def cpu_baseline(scene):
     return {"value": round(scene.W * scene.H / dt / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
             "sample": f"one full frame of the same workload ({scene.means3D.shape[0]} Gaussians, "
                       f"{scene.W}x{scene.H}, fwd+bwd), {dt:.2f} s wall",
-            "reference_python_loop": "19.48 s for 10k Gaussians 200x200 (0.00205 Mpix/s, BASELINE.md, 8 cores)"}
+            "reference_python_loop": "19.48 s for 10k Gaussians 200x200 (0.00205 Mpix/s, BASELINE.md, 8 cores)",
+            "torch_loop_port_config1": cpu_baseline_torch_loop()}
+
+
+def cpu_baseline_torch_loop(n_sample=1500):
+    """the build's PyTorch-CPU restatement of the reference's per-Gaussian loop
+    (oracle/torch_loop_oracle.py, pinned against the reference's goldens) on a bounded sample of config 1
+    (10 k Gaussians, SH degree 0, 200x200): the loop costs the same per Gaussian whatever N is."""
+    from oracle import torch_loop_oracle as tl
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    sc = syn.make_scene(n_sample, 1, 200, 200, seed=0)
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs[:, 0, :], sc.opacities, sc.scales, sc.rotations)]
+    t0 = time.perf_counter()
+    img, _, _ = tl.render(*leaves, sc.viewmatrix, sc.projmatrix, sc.bg, 200, 200)
+    t1 = time.perf_counter()
+    (img * sc.G).sum().backward()
+    t2 = time.perf_counter()
+    per = (t2 - t0) / n_sample
+    return {"ms_per_gaussian": round(per * 1e3, 3), "fwd_s": round(t1 - t0, 2), "bwd_s": round(t2 - t1, 2),
+            "threads": torch.get_num_threads(), "sample": f"{n_sample} of config 1's 10 000 Gaussians, 200x200, SH degree 0",
+            "config1_extrapolated": {"seconds": round(per * 10000, 1), "Mpix_per_s": round(0.04 / (per * 10000), 5),
+                                     "note": "linear in the number of Gaussians (SURVEY.md section 6: 1 000 -> 1.9 s, 10 000 -> 19.5 s)"}}
 
 
 if __name__ == "__main__":

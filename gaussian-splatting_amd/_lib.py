@@ -34,8 +34,9 @@ PROTOTYPES = {
     "gs_last_error": (C.c_char_p, []),
     "gs_tile_size": (_i, []),
     "gs_grad_row_floats": (_i, []),
-    "gs_preprocess_fwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 16 + [_i, _i, _vp]),
-    "gs_preprocess_bwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 20 + [_i, _vp]),
+    "gs_sh_jac_row_floats": (_i, []),
+    "gs_preprocess_fwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 16 + [_i, _i, _vp, _vp]),
+    "gs_preprocess_bwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 20 + [_i, _vp, _vp]),
     "gs_scan_workspace_bytes": (_sz, [_ll]),
     "gs_scan_tiles": (_i, [_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "gs_duplicate_with_keys": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),

@@ -22,3 +22,4 @@ extern "C" int gs_version(void) { return 100; }  // 0.1.0
 extern "C" int gs_tile_size(void) { return GS_TILE; }
 
 extern "C" int gs_grad_row_floats(void) { return GS_GRAD_ROW; }
+extern "C" int gs_sh_jac_row_floats(void) { return GS_SH_JAC_ROW; }

@@ -34,6 +34,7 @@
 #define GS_TILE 16          // tile edge in pixels (keys, ranges)
 #define GS_SUB 8            // one wave64 owns an 8x8 sub-tile
 #define GS_BLOCK 256        // threads per tile workgroup = 4 waves
+#define GS_SH_JAC_ROW 12     // floats per row of the forward's colour side table (layout: preprocess.hip, include/gsplat.h)
 #ifndef GS_GRAD_ROW
 #define GS_GRAD_ROW 16      // floats per gradient row (see above; the rows are read as float4s)
 #endif

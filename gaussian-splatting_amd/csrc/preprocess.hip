@@ -148,8 +148,12 @@ __device__ __forceinline__ void project_gaussian(int i, int H, int W, int row_b,
     }
 }
 
+// Contraction is off here and where the colour is summed: whether a product feeds an fma depends on how many uses it has
+// after inlining, and the instantiations (with / without the side table, forward / backward) must all produce the same
+// colour bit for bit -- the image of a forward with and without a backward to follow, and the clamp mask.
 template <int DEG>
 __device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+#pragma clang fp contract(off)
     b[0] = SH_C0;
     if (DEG > 0) {
         b[1] = -SH_C1 * y;
@@ -227,7 +231,16 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int i, in
     }
 }
 
-template <int DEG, bool VEC4>
+// Layout of the optional colour side table sh_jac: one 48-byte row (three float4) per Gaussian, only rows of drawn
+// Gaussians are written / read:
+//   floats 0..8  W[a][c] = sum_k (d basis_k / d dir_a) sh_kc at 3 a + c  (a = x, y, z of the unit view direction; c = r, g, b)
+//   word   9     bit c set: channel c was inside the clamp [0, 1] (its gradient passes, gaussian_renderer/__init__.py:206)
+//   words 10, 11 unused (row padded to whole 16-byte words)
+// With it the backward needs no second pass over the N x K x 3 coefficients: d colour / d dir is W, d/d sh is basis x
+// colour gradient.  Written by the forward in the order the backward's own pass would have summed it.
+static_assert(GS_SH_JAC_ROW == 12, "nine Jacobian entries + the clamp mask, padded to three float4");
+
+template <int DEG, bool VEC4, bool JAC>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     int N, int K, int H, int W, int row_b, int row_e, const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, const float* __restrict__ means3D,
@@ -235,7 +248,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     const float* __restrict__ cov6, const float* __restrict__ opacities,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids, uint2* __restrict__ rects) {
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids, uint2* __restrict__ rects,
+    float4* __restrict__ sh_jac) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     Geom g;
@@ -264,13 +278,32 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-7f;
         dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
         sh_basis<DEG>(dx, dy, dz, b);
+        uint32_t pass = 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+#pragma clang fp contract(off)     // one rounding sequence in every instantiation: see sh_basis
             float v = 0.0f;
 #pragma unroll
             for (int k = 0; k < NB; ++k) v += b[k] * sh[3 * k + c];
             v += 0.5f;
             rgb[c] = fminf(fmaxf(v, 0.0f), 1.0f);
+            if (v >= 0.0f && v <= 1.0f) pass |= 1u << c;
+        }
+        if (JAC) {
+            float bg[NB][3];
+            sh_basis_grad<DEG>(dx, dy, dz, bg);
+            float Wm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int f = 0; f < NB * 3; ++f) {
+                const int k = f / 3, c = f % 3;
+                Wm[0][c] += bg[k][0] * sh[f];
+                Wm[1][c] += bg[k][1] * sh[f];
+                Wm[2][c] += bg[k][2] * sh[f];
+            }
+            float4* jp = sh_jac + 3 * (size_t)i;
+            jp[0] = make_float4(Wm[0][0], Wm[0][1], Wm[0][2], Wm[1][0]);
+            jp[1] = make_float4(Wm[1][1], Wm[1][2], Wm[2][0], Wm[2][1]);
+            jp[2] = make_float4(Wm[2][2], __uint_as_float(pass), 0.0f, 0.0f);
         }
     }
     const uint32_t rx = (uint32_t)g.xmin | ((uint32_t)g.xmax << 16);
@@ -291,7 +324,10 @@ constexpr int BWD_STAGE_STRIDE = BWD_STAGE_MAX_ROW + 1;   // odd stride: per-lan
 // (2 waves per SIMD: latency-bound), so the staged mode runs as two launches instead:
 // PART 1 = everything but the SH colours (126 VGPRs), PART 2 = the SH part alone, which adds its
 // share of d/d means3D to what PART 1 wrote.
-template <int DEG, int MODE, int PART>
+// JAC (with MODE 2, PART 0 only): the forward left d colour / d dir and the clamp mask in sh_jac (layout above preprocess_fwd_kernel), so
+// the SH coefficients are not read again; the SH part is then light enough (16 basis values, no 48-float pass) to run in
+// the geometry launch: one kernel, one read of every row, no read-modify-write of d/d means3D.
+template <int DEG, int MODE, int PART, bool JAC = false>
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int N, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, const float* __restrict__ means3D,
@@ -301,7 +337,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const float4* __restrict__ grad_rows, float* __restrict__ g_means3D,
     float* __restrict__ g_means2D, float* __restrict__ g_scales, float* __restrict__ g_rots,
     float* __restrict__ g_cov6, float* __restrict__ g_opac, float* __restrict__ g_shs,
-    float* __restrict__ g_colors, bool acc) {
+    float* __restrict__ g_colors, bool acc, const float4* __restrict__ sh_jac) {
+    static_assert(!JAC || (MODE == 2 && PART == 0), "the side-table form is the staged single launch");
     // acc: add this view's gradients to what the outputs hold (drawn Gaussians only; g_means2D, a
     // per-view statistic, is always overwritten) instead of overwriting them
     constexpr bool VEC4 = MODE >= 1;
@@ -328,7 +365,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int RL = 3 * K;
     const int i0 = i - lane;                      // first Gaussian of this wave
     const int nq = STAGE && i0 < N ? ((N - i0 < 64 ? N - i0 : 64) * RL) / 4 : 0;   // float4s in the chunk
-    if (STAGE && shs && PART != 1) {
+    if (STAGE && shs && PART != 1 && !JAC) {
         const uint64_t dmask = __ballot(drawn);
         const float4* p4 = reinterpret_cast<const float4*>(shs + (size_t)i0 * RL);
         for (int m = lane; m < nq; m += 64) {
@@ -383,16 +420,30 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         if (colors_precomp) {
             gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
         } else if (shs && PART != 1) {
-            float b[NB], bg[NB][3];
+            float b[NB];
             const float vx = px - campos[0], vy = py - campos[1], vz = pz - campos[2];
             const float n = sqrtf(vx * vx + vy * vy + vz * vz);
             const float ne = n + 1e-7f;
             const float dx = vx / ne, dy = vy / ne, dz = vz / ne;
             sh_basis<DEG>(dx, dy, dz, b);
-            sh_basis_grad<DEG>(dx, dy, dz, bg);
             const float dcol[3] = {d_r, d_g, d_bl};
             float gcl[3];
             float ddir[3] = {0.f, 0.f, 0.f};
+            if (JAC) {
+                // W = d colour / d dir and the clamp mask as the forward left them
+                const float4* jp = sh_jac + 3 * (size_t)i;
+                const float4 j0 = jp[0], j1 = jp[1], j2 = jp[2];
+                const float Wm[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
+                const uint32_t pass = __float_as_uint(j2.y);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gcl[c] = ((pass >> c) & 1u) ? dcol[c] : 0.0f;
+#pragma unroll
+                    for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
+                }
+            } else {
+            float bg[NB][3];
+            sh_basis_grad<DEG>(dx, dy, dz, bg);
             // one streaming pass over the coefficients (each loaded value is consumed at once, so the
             // 48 floats never sit in registers together): colour v[c] = sum_k b_k sh_kc and
             // Wm[a][c] = sum_k (d b_k / d dir_a) sh_kc; the clamp mask is applied afterwards
@@ -408,6 +459,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 for (int v = 0; v < NV; ++v) t4[v] = p4[v];
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
+#pragma clang fp contract(off)     // the colour must round as in the forward (clamp mask)
                     float val;
                     if (STAGE) {
                         val = st_row[f];
@@ -430,6 +482,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 gcl[c] = (v >= 0.0f && v <= 1.0f) ? dcol[c] : 0.0f;
 #pragma unroll
                 for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
+            }
             }
             if (gsh_out && STAGE) {
 #pragma unroll
@@ -630,14 +683,18 @@ int launch_fwd(bool vec4, int N, int K, int H, int W, int row_b, int row_e, cons
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* opac, const float* shs, const float* colors,
                float4* splat, int32_t* radii, uint32_t* tiles, uint32_t* depth_keys, uint32_t* ids, uint2* rects,
-               hipStream_t stream) {
+               float4* sh_jac, hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
-    if (vec4)
-        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, true>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
-                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids, rects);
-    else
-        hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, false>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, proj,
-                           campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys, ids, rects);
+#define GS_LAUNCH_FWD(VEC4, JAC)                                                                                      \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<DEG, VEC4, JAC>), grid, block, 0, stream, N, K, H, W, row_b, row_e, view, \
+                       proj, campos, means3D, scales, rots, cov6, opac, shs, colors, splat, radii, tiles, depth_keys,  \
+                       ids, rects, sh_jac)
+    const bool jac = sh_jac != nullptr && shs != nullptr;
+    if (vec4 && jac) GS_LAUNCH_FWD(true, true);
+    else if (vec4) GS_LAUNCH_FWD(true, false);
+    else if (jac) GS_LAUNCH_FWD(false, true);
+    else GS_LAUNCH_FWD(false, false);
+#undef GS_LAUNCH_FWD
     GS_CHECK_LAUNCH("preprocess_fwd");
     return GS_OK;
 }
@@ -647,13 +704,16 @@ int launch_bwd(int mode, int N, int K, int H, int W, const float* view, const fl
                const float* campos, const float* means3D, const float* scales, const float* rots,
                const float* cov6, const float* opac, const float* shs, const float* colors, const int32_t* radii,
                const float4* rows, float* g_means3D, float* g_means2D, float* g_scales, float* g_rots,
-               float* g_cov6, float* g_opac, float* g_shs, float* g_colors, bool acc, hipStream_t stream) {
+               float* g_cov6, float* g_opac, float* g_shs, float* g_colors, bool acc, const float4* sh_jac,
+               hipStream_t stream) {
     const dim3 grid(gs_div_up(N, 256)), block(256);
-#define GS_LAUNCH_BWD(D_, MODE, PART)                                                                            \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<D_, MODE, PART>), grid, block, 0, stream, N, K, H, W, view, proj,     \
+#define GS_LAUNCH_BWD(D_, MODE, PART, ...)                                                                       \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<D_, MODE, PART, ##__VA_ARGS__>), grid, block, 0, stream, N, K, H, W, view, proj, \
                        campos, means3D, scales, rots, cov6, opac, shs, colors, radii, rows, g_means3D, g_means2D,  \
-                       g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors, acc)
-    if (mode == 2) {
+                       g_scales, g_rots, g_cov6, g_opac, g_shs, g_colors, acc, sh_jac)
+    if (mode == 2 && sh_jac && shs) {
+        GS_LAUNCH_BWD(DEG, 2, 0, true);
+    } else if (mode == 2) {
         GS_LAUNCH_BWD(0, 0, 1);
         GS_CHECK_LAUNCH("preprocess_bwd (geometry)");
         GS_LAUNCH_BWD(DEG, 2, 2);
@@ -685,7 +745,8 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
                                  const float* scales, const float* rotations, const float* cov3D_precomp,
                                  const float* opacities, const float* shs, const float* colors_precomp,
                                  void* splat, int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                                 uint32_t* ids, void* rects, int tile_row_begin, int tile_row_end, void* stream_) {
+                                 uint32_t* ids, void* rects, int tile_row_begin, int tile_row_end, float* sh_jac,
+                                 void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
@@ -696,16 +757,17 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
                "depth_keys, ids and rects go together");
     GS_REQUIRE(((uintptr_t)rects & 7) == 0, "rects must be 8-byte aligned");
     GS_REQUIRE(tile_row_begin >= 0 && tile_row_end >= tile_row_begin, "bad tile row band [%d,%d)", tile_row_begin, tile_row_end);
+    GS_REQUIRE(((uintptr_t)sh_jac & 15) == 0, "sh_jac must be 16-byte aligned");
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0);
     const int deg = shs ? sh_degree : 0;
     float4* sp = (float4*)splat;
     switch (deg) {
-        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
-        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
-        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
-        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, stream);
+        case 0: return launch_fwd<0>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, (float4*)sh_jac, stream);
+        case 1: return launch_fwd<1>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, (float4*)sh_jac, stream);
+        case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, (float4*)sh_jac, stream);
+        default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, (float4*)sh_jac, stream);
     }
 }
 
@@ -715,7 +777,8 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
                                  const float* opacities, const float* shs, const float* colors_precomp,
                                  const int32_t* radii, const float* grad_rows, float* g_means3D, float* g_means2D,
                                  float* g_scales, float* g_rotations, float* g_cov3D, float* g_opacities,
-                                 float* g_shs, float* g_colors, int accumulate, void* stream_) {
+                                 float* g_shs, float* g_colors, int accumulate, const float* sh_jac,
+                                 void* stream_) {
     if (N == 0) return GS_OK;
     int rc = check_common(N, K, sh_degree, H, W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
     if (rc) return rc;
@@ -723,6 +786,7 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
     GS_REQUIRE(((uintptr_t)grad_rows & 15) == 0, "grad_rows must be 16-byte aligned");
     GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
     GS_REQUIRE(!g_rotations || ((uintptr_t)g_rotations & 15) == 0, "g_rotations must be 16-byte aligned");
+    GS_REQUIRE(((uintptr_t)sh_jac & 15) == 0, "sh_jac must be 16-byte aligned");
     if (N == 0) return GS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0) && (((uintptr_t)g_shs & 15) == 0);
@@ -730,9 +794,9 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
     const int deg = shs ? sh_degree : 0;
     const float4* rows = (const float4*)grad_rows;
     switch (deg) {
-        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
-        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
-        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
-        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, stream);
+        case 0: return launch_bwd<0>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, (const float4*)sh_jac, stream);
+        case 1: return launch_bwd<1>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, (const float4*)sh_jac, stream);
+        case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, (const float4*)sh_jac, stream);
+        default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, (const float4*)sh_jac, stream);
     }
 }

@@ -403,10 +403,11 @@ class _RasterizeReplicated(torch.autograd.Function):
         with torch.cuda.device(dev):
             band = R._band(settings, None)
             state = R.preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                         colors_precomp, None)
+                                         colors_precomp, None, want_jac=need_grad)
             image, depth, alpha, aux, rows = R.render_forward(settings, state.splat, state.ranges, state.point_list,
                                                               need_grad, t_eps, band)
         ctx.rows, ctx.settings, ctx.t_eps, ctx.band, ctx.owner = rows, settings, float(t_eps), band, owner
+        ctx.sh_jac = state.sh_jac
         ctx.set_materialize_grads(False)
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
@@ -464,13 +465,15 @@ class _RasterizeReplicated(torch.autograd.Function):
             g_m3, g_m2, g_sh, g_col, g_op, g_sc, g_rot, g_cov = full
             if not m2d_rows:
                 g_m2 = None
+            jac = ctx.sh_jac if shs is not None else None     # (N, 12): a range is a row slice like everything else
             for (b, e) in bucket_ranges(N, owner.num_buckets):
                 with _stage("preprocess_bwd"):
                     R._lib.check(lib.gs_preprocess_bwd(
                         e - b, K, settings.sh_degree, H, W, *cam_p, at(means3D, b), at(scales, b), at(rotations, b),
                         at(cov3D_precomp, b), at(opacities, b), at(shs, b), at(colors_precomp, b), at(radii, b), at(rows, b),
                         at(g_m3, b), at(g_m2, b), at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b), at(g_sh, b),
-                        at(g_col, b), 0, st), "gs_preprocess_bwd")
+                        at(g_col, b), 0, at(jac, b), st),
+                        "gs_preprocess_bwd")
                 if reduce_now:      # queued behind this range's launches on RCCL's stream; the next range's kernels overlap it
                     with _stage("allreduce_launch"):
                         works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],

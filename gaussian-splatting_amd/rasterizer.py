@@ -91,6 +91,7 @@ class BinningState(NamedTuple):
     keys: torch.Tensor           # (D,) tile id per sorted pair (int32 storage)
     point_list: torch.Tensor     # (D,) Gaussian index per sorted pair (int32 storage)
     ranges: torch.Tensor         # (tiles,2) i32
+    sh_jac: Optional[torch.Tensor] = None   # (N,12) f32: the forward's colour side table for the backward (gsplat.h)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -139,11 +140,26 @@ def _band(settings, tile_rows):
     return b, e
 
 
+def sh_jac_row_floats() -> int:
+    """Floats per row of the forward's colour side table (gs_sh_jac_row_floats)."""
+    return int(_lib.load().gs_sh_jac_row_floats())
+
+
+def _jac_ptr(sh_jac, N):
+    """Pointer of the colour side table for the C-ABI; NULL without one."""
+    if sh_jac is None:
+        return None
+    if sh_jac.dtype != torch.float32 or tuple(sh_jac.shape) != (N, sh_jac_row_floats()) or not sh_jac.is_contiguous():
+        raise ValueError(f"sh_jac must be a contiguous float32 (N,{sh_jac_row_floats()}) tensor")
+    return _ptr(sh_jac)
+
+
 def preprocess(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-               colors_precomp, tile_rows=None, out=None):
+               colors_precomp, tile_rows=None, out=None, sh_jac=None):
     """gs_preprocess_fwd on the current stream.  Returns (splat (N,12), radii, tiles_touched, dkeys (N,),
     ids (N,), rects (N,2)).  `out` = preallocated contiguous (splat, dkeys, ids, rects) to write into
-    (rows of the sort's ping-pong buffers, or slices of an exchange buffer: parallel.SplatExchange)."""
+    (rows of the sort's ping-pong buffers, or slices of an exchange buffer: parallel.SplatExchange).
+    sh_jac = a (N, gs_sh_jac_row_floats()) float32 tensor to receive the colour side table (shs only)."""
     lib = _lib.load()
     dev = means3D.device
     N = means3D.shape[0]
@@ -163,18 +179,25 @@ def preprocess(settings: GaussianRasterizationSettings, means3D, opacities, scal
         raise ValueError("preprocess: output buffers must be contiguous (N,12), (N,), (N,), (N,2)")
     radii = torch.empty((N,), **i32)
     tiles_touched = torch.empty((N,), **i32)
+    jac_p = _jac_ptr(sh_jac if shs is not None else None, N)
     with _stage("preprocess_fwd"):
         _lib.check(lib.gs_preprocess_fwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(splat),
                                          _ptr(radii), _ptr(tiles_touched), _ptr(dkeys), _ptr(ids),
-                                         _ptr(rects), row_b, row_e, _stream()), "gs_preprocess_fwd")
+                                         _ptr(rects), row_b, row_e, jac_p, _stream()), "gs_preprocess_fwd")
     return splat, radii, tiles_touched, dkeys, ids, rects
 
 
+# the forward leaves d colour / d dir for the backward (one backward launch that never re-reads the coefficients);
+# False = the two-launch backward that does (kept for callers of the C-ABI that pass no table)
+USE_SH_JAC = True
+
+
 def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
-                       cov3D_precomp, shs, colors_precomp, tile_rows=None) -> BinningState:
-    """preprocess -> depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges (current stream)."""
+                       cov3D_precomp, shs, colors_precomp, tile_rows=None, want_jac=False) -> BinningState:
+    """preprocess -> depth sort -> scan -> duplicate_with_keys -> tile sort -> tile ranges (current stream).
+    want_jac: a backward will follow -- with shs, also write the colour side table (BinningState.sh_jac)."""
     dev = means3D.device
     N = means3D.shape[0]
     i32 = dict(dtype=torch.int32, device=dev)
@@ -183,9 +206,13 @@ def preprocess_and_bin(settings: GaussianRasterizationSettings, means3D, opaciti
     ids = torch.empty((2, max(N, 1)), **i32)
     splat = torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N]
     rects = torch.empty((max(N, 1), 2), **i32)[:N]
+    sh_jac = None
+    if want_jac and USE_SH_JAC and shs is not None and N > 0:
+        sh_jac = torch.empty((N, sh_jac_row_floats()), dtype=torch.float32, device=dev)
     _, radii, tiles_touched, _, _, _ = preprocess(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                                  colors_precomp, tile_rows, out=(splat, dkeys[0][:N], ids[0][:N], rects))
-    return bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows)
+                                                  colors_precomp, tile_rows, out=(splat, dkeys[0][:N], ids[0][:N], rects),
+                                                  sh_jac=sh_jac)
+    return bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows)._replace(sh_jac=sh_jac)
 
 
 def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_rows=None, before_scan=None) -> BinningState:
@@ -380,13 +407,14 @@ def render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_im
 
 
 def preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp, radii,
-                        rows, needs, means2D_shape, accumulate_into=None, out=None):
+                        rows, needs, means2D_shape, accumulate_into=None, out=None, sh_jac=None):
     """gs_preprocess_bwd on the current stream.  `needs` = 8 flags in the order of GaussianRasterizer.forward's
     arguments; returns the 8 gradients (None where not needed).  accumulate_into = the 8-tuple a previous
     call returned: this view's gradients are added into those tensors (means2D's, per view, is fresh).
     out = an 8-tuple of preallocated destinations (None where not needed) that this call OVERWRITES: row
     slices of full-size gradient tensors when the chain rule runs per Gaussian range (every per-Gaussian
-    argument is then the same row slice; parallel.ViewShardedRasterizer)."""
+    argument is then the same row slice; parallel.ViewShardedRasterizer).
+    sh_jac = the side table the forward wrote for these Gaussians and this view (BinningState.sh_jac), or None."""
     lib = _lib.load()
     dev = means3D.device
     N = means3D.shape[0]
@@ -414,13 +442,14 @@ def preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_p
         g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
         g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
         g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
+    jac_p = _jac_ptr(sh_jac if shs is not None else None, N)
     with _stage("preprocess_bwd"):
         _lib.check(lib.gs_preprocess_bwd(N, K, settings.sh_degree, H, W, _ptr(view), _ptr(proj), _ptr(campos),
                                          _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp),
                                          _ptr(opacities), _ptr(shs), _ptr(colors_precomp), _ptr(radii), _ptr(rows),
                                          _ptr(g_means3D), _ptr(g_means2D), _ptr(g_scales), _ptr(g_rots),
                                          _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors),
-                                         0 if accumulate_into is None else 1, _stream()),
+                                         0 if accumulate_into is None else 1, jac_p, _stream()),
                    "gs_preprocess_bwd")
     if needs[1] and g_means2D is None and means2D_shape is not None:
         g_means2D = torch.zeros(means2D_shape, **f32)
@@ -435,10 +464,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             band = _band(settings, tile_rows)
             state = preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                       colors_precomp, tile_rows)
+                                       colors_precomp, tile_rows, want_jac=need_grad)
             image, depth, alpha, aux, rows = render_forward(settings, state.splat, state.ranges, state.point_list,
                                                             need_grad, t_eps, band)
         ctx.rows = rows
+        ctx.sh_jac = state.sh_jac          # scratch of this forward/backward pair, like rows
         ctx.set_materialize_grads(False)   # unused outputs (depth, alpha) arrive as None, not as zero fills
         ctx.settings = settings
         ctx.t_eps = float(t_eps)
@@ -472,7 +502,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             rows = render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_image, g_depth, g_alpha,
                                    rows, ctx.t_eps, ctx.band)
             grads = preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                        colors_precomp, radii, rows, ctx.needs_input_grad, ctx.means2D_shape)
+                                        colors_precomp, radii, rows, ctx.needs_input_grad, ctx.means2D_shape,
+                                        sh_jac=ctx.sh_jac)
         return (*grads, None, None, None, None)
 
 

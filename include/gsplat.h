@@ -59,13 +59,21 @@ int gs_grad_row_floats(void);    /* 16: floats (4-byte units) per per-Gaussian g
  * rects (N x 2 uint32: x_min | x_max << 16, y_min | y_max << 16; all zero when not drawn), all three
  * or none NULL: input of the binning stage, depth_keys[i] = 32-bit key whose
  * ascending order is descending depth (0xFFFFFFFF for Gaussians that are not drawn, so they sort last), ids[i] = i.
+ * sh_jac (optional, NULL = not wanted; only with shs; 16-byte aligned): side table for gs_preprocess_bwd, one row of
+ * gs_sh_jac_row_floats() = 12 floats (48 bytes) per Gaussian (rows of Gaussians that are not drawn are left
+ * unwritten): floats 0..8 = d colour_c / d dir_a = sum_k (d basis_k / d dir_a) sh_kc at index 3 a + c (the
+ * view-direction Jacobian autograd forms from utils/sh_utils.py:40-96), word 9 = bit c set when channel c was inside
+ * the clamp of gaussian_renderer/__init__.py:206, words 10..11 unused.  With it the backward does not read the
+ * N x K x 3 coefficients a second time.
  */
+int gs_sh_jac_row_floats(void);
 int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                       const float* projmatrix, const float* campos, const float* means3D,
                       const float* scales, const float* rotations, const float* cov3D_precomp,
                       const float* opacities, const float* shs, const float* colors_precomp,
                       void* splat, int32_t* radii, uint32_t* tiles_touched, uint32_t* depth_keys,
-                      uint32_t* ids, void* rects, int tile_row_begin, int tile_row_end, void* stream);
+                      uint32_t* ids, void* rects, int tile_row_begin, int tile_row_end, float* sh_jac,
+                      void* stream);
 
 /*
  * Binning stage.  The reference has one global far-to-near order (torch.argsort at
@@ -161,6 +169,9 @@ int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const
  * their own, as the multi-view step of parallel.SplatExchange does (no counterpart in the reference,
  * which renders one view per iteration, train.py:129-135).  g_means2D is a per-view statistic and is
  * overwritten either way.
+ * sh_jac (optional): the table gs_preprocess_fwd wrote for the same Gaussians, view and shs.
+ * Given (and shs rows of at most 48 floats, 16-byte aligned), the whole chain rule runs as ONE launch that
+ * never reads shs; NULL = two launches, the second of which re-reads the coefficients.
  */
 int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,
                       const float* projmatrix, const float* campos, const float* means3D,
@@ -168,7 +179,7 @@ int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* vi
                       const float* opacities, const float* shs, const float* colors_precomp, const int32_t* radii,
                       const float* grad_rows, float* g_means3D, float* g_means2D, float* g_scales,
                       float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
-                      float* g_colors_precomp, int accumulate, void* stream);
+                      float* g_colors_precomp, int accumulate, const float* sh_jac, void* stream);
 
 /*
  * Training loss, fused (the step right after the rasterizer in every iteration).

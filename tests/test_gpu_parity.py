@@ -466,16 +466,20 @@ def test_tile_row_bands_backward_adds_up(dgr):
             check_grad(f"bands{world}:d_{k}", banded[k], full[k], rel=2e-5)   # fp32 summation order only
 
 
-@pytest.mark.parametrize("variant", ["sh_deg0_scalar", "sh_deg3_staged", "sh_deg3_K20_vec4", "colors_cov3d"])
+@pytest.mark.parametrize("variant", ["sh_deg0_scalar", "sh_deg3_staged", "sh_deg3_K20_vec4", "colors_cov3d",
+                                     "sh_deg3_jac", "sh_deg1_jac"])
 def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
     """accumulate flag of gs_preprocess_bwd (multi-view batches, parallel.SplatExchange): two views with
-    the flag == the sum of the two views' own gradients; Gaussians culled in the second view keep the first's."""
+    the flag == the sum of the two views' own gradients; Gaussians culled in the second view keep the first's.
+    *_jac: the single-launch form fed by the forward's colour side table (sh_jac), which must also agree with the
+    two-launch form that re-reads the coefficients."""
     R = importlib.import_module("gaussian-splatting_amd.rasterizer")
     syn = importlib.import_module("gaussian-splatting_amd.synthetic")
     dev = torch.device("cuda:0")
     N, H, W = 5000, 120, 168
     K, deg = {"sh_deg0_scalar": (1, 0), "sh_deg3_staged": (16, 3), "sh_deg3_K20_vec4": (20, 3),
-              "colors_cov3d": (1, 0)}[variant]
+              "colors_cov3d": (1, 0), "sh_deg3_jac": (16, 3), "sh_deg1_jac": (4, 1)}[variant]
+    use_jac = variant.endswith("_jac")
     sc = syn.make_scene(N, K, H, W, seed=11, sh_degree=deg)
     views = [syn.jitter_view(sc, 0), syn.jitter_view(sc, 5)]
     m3, sh, op, s, q = (getattr(sc, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
@@ -492,19 +496,34 @@ def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
                       torch.randn(N, 4, generator=gr)], dim=1).contiguous().to(dev)
     assert rows.shape == (N, R.grad_row_floats())
     needs = [True] * 8
-    per_view, radii = [], []
+    per_view, radii, jacs = [], [], []
     for v in views:
         st = _scene_settings(dgr, v, dev)
-        _, r, *_ = R.preprocess(st, m3, op, s, q, cov6, sh, colors)
+        jac = torch.full((N, R.sh_jac_row_floats()), float("nan"), device=dev) if use_jac else None
+        _, r, *_ = R.preprocess(st, m3, op, s, q, cov6, sh, colors, sh_jac=jac)
         radii.append(r)
-        per_view.append(R.preprocess_backward(st, m3, op, s, q, cov6, sh, colors, r, rows, needs, (N, 3)))
+        jacs.append(jac)
+        per_view.append(R.preprocess_backward(st, m3, op, s, q, cov6, sh, colors, r, rows, needs, (N, 3), sh_jac=jac))
     assert int(((radii[0] > 0) != (radii[1] > 0)).sum()) > 0      # some Gaussians are drawn in one view only
     acc = None
-    for v, r in zip(views, radii):
+    for v, r, jac in zip(views, radii, jacs):
         acc = R.preprocess_backward(_scene_settings(dgr, v, dev), m3, op, s, q, cov6, sh, colors, r, rows, needs, (N, 3),
-                                    accumulate_into=acc)
+                                    accumulate_into=acc, sh_jac=jac)
     torch.cuda.synchronize()
     names = ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "cov3D")
+    if use_jac:
+        for v, r, got in zip(views, radii, per_view):
+            two_launch = R.preprocess_backward(_scene_settings(dgr, v, dev), m3, op, s, q, cov6, sh, colors, r, rows,
+                                               needs, (N, 3))
+            for k, name in enumerate(names):
+                if got[k] is None:
+                    assert two_launch[k] is None
+                    continue
+                assert torch.isfinite(got[k]).all(), name
+                if name == "means3D":   # the colour share is summed into the geometry share in another order
+                    assert (got[k] - two_launch[k]).abs().max().item() <= 2e-6 * two_launch[k].abs().max().item()
+                else:
+                    assert torch.equal(got[k], two_launch[k]), name
     for k, name in enumerate(names):
         a, b = per_view[0][k], per_view[1][k]
         if a is None:

@@ -210,6 +210,45 @@ __device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float (
     }
 }
 
+// W[a][c] = sum_k (d basis_k / d dir_a) sh_kc for the coefficient row sh (k-major triples): sh_basis_grad contracted with
+// the coefficients, written out term by term so that the 15 structurally zero derivatives cost nothing and no 16 x 3
+// table has to live in registers next to the 48 coefficients.  (Register note for this file: the build passes
+// -fno-slp-vectorize -- packing these scalar chains into v_pk_fma_f32 gains nothing on gfx950, where the packed form
+// issues at half rate, and its shuffles cost the forward kernel 138 VGPRs instead of 58.)
+template <int DEG>
+__device__ __forceinline__ void sh_dir_jacobian(float x, float y, float z, const float* sh, float (*Wm)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) Wm[a][0] = Wm[a][1] = Wm[a][2] = 0.0f;
+    auto add = [&](int a, int k, float g) {
+        Wm[a][0] += g * sh[3 * k];
+        Wm[a][1] += g * sh[3 * k + 1];
+        Wm[a][2] += g * sh[3 * k + 2];
+    };
+    if (DEG > 0) {
+        add(1, 1, -SH_C1);
+        add(2, 2, SH_C1);
+        add(0, 3, -SH_C1);
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        add(0, 4, SH_C2_0 * y); add(1, 4, SH_C2_0 * x);
+        add(1, 5, SH_C2_1 * z); add(2, 5, SH_C2_1 * y);
+        add(0, 6, SH_C2_2 * -2.0f * x); add(1, 6, SH_C2_2 * -2.0f * y); add(2, 6, SH_C2_2 * 4.0f * z);
+        add(0, 7, SH_C2_3 * z); add(2, 7, SH_C2_3 * x);
+        add(0, 8, SH_C2_4 * 2.0f * x); add(1, 8, SH_C2_4 * -2.0f * y);
+        if (DEG > 2) {
+            add(0, 9, SH_C3_0 * 6.0f * xy); add(1, 9, SH_C3_0 * (3.0f * xx - 3.0f * yy));
+            add(0, 10, SH_C3_1 * yz); add(1, 10, SH_C3_1 * xz); add(2, 10, SH_C3_1 * xy);
+            add(0, 11, SH_C3_2 * -2.0f * xy); add(1, 11, SH_C3_2 * (4.0f * zz - xx - 3.0f * yy)); add(2, 11, SH_C3_2 * 8.0f * yz);
+            add(0, 12, SH_C3_3 * -6.0f * xz); add(1, 12, SH_C3_3 * -6.0f * yz);
+            add(2, 12, SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+            add(0, 13, SH_C3_4 * (4.0f * zz - 3.0f * xx - yy)); add(1, 13, SH_C3_4 * -2.0f * xy); add(2, 13, SH_C3_4 * 8.0f * xz);
+            add(0, 14, SH_C3_5 * 2.0f * xz); add(1, 14, SH_C3_5 * -2.0f * yz); add(2, 14, SH_C3_5 * (xx - yy));
+            add(0, 15, SH_C3_6 * (3.0f * xx - 3.0f * yy)); add(1, 15, SH_C3_6 * -6.0f * xy);
+        }
+    }
+}
+
 // loads the first NB coefficient triples of Gaussian i; VEC4: rows are 16-byte aligned multiples of 16 B
 template <int NB, bool VEC4>
 __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int i, int K, float* sh) {
@@ -250,20 +289,47 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids, uint2* __restrict__ rects,
     float4* __restrict__ sh_jac) {
+    // Output rows (48-byte records, 48-byte side-table rows) leave through LDS: a wave's 64 rows are 3 KB of
+    // consecutive memory, written as three 1 KB store instructions of whole lines.  One 16-byte store per lane and
+    // row word instead (48-byte lane stride) leaves every 128-byte line in three partial pieces, which cost this
+    // HBM-bound kernel 0.18 -> 0.30 ms once a second table was written that way.
+    __shared__ float4 out_stage[4][64 * 3];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const int lane = threadIdx.x & 63;
+    float4* st = out_stage[threadIdx.x >> 6];
+    const bool in_range = i < N;
+    bool drawn = false;
     Geom g;
-    project_gaussian(i, H, W, row_b, row_e, view, proj, means3D, scales, rots, cov6, g);
-    radii[i] = g.radius;
-    tiles_touched[i] = g.tiles;
-    if (depth_keys) {   // input of the per-Gaussian depth sort; culled Gaussians sort last
-        depth_keys[i] = g.drawn ? gs_depth_key_desc(g.cam[2]) : 0xFFFFFFFFu;
-        ids[i] = (uint32_t)i;
-        // compact copy of the box (all zero when not drawn) for the binning stage's one gather
-        rects[i] = make_uint2((uint32_t)g.xmin | ((uint32_t)g.xmax << 16), (uint32_t)g.ymin | ((uint32_t)g.ymax << 16));
+    if (in_range) {
+        project_gaussian(i, H, W, row_b, row_e, view, proj, means3D, scales, rots, cov6, g);
+        drawn = g.drawn;
+        radii[i] = g.radius;
+        tiles_touched[i] = g.tiles;
+        if (depth_keys) {   // input of the per-Gaussian depth sort; culled Gaussians sort last
+            depth_keys[i] = g.drawn ? gs_depth_key_desc(g.cam[2]) : 0xFFFFFFFFu;
+            ids[i] = (uint32_t)i;
+            // compact copy of the box (all zero when not drawn) for the binning stage's one gather
+            rects[i] = make_uint2((uint32_t)g.xmin | ((uint32_t)g.xmax << 16), (uint32_t)g.ymin | ((uint32_t)g.ymax << 16));
+        }
     }
-    if (!g.drawn) return;
-    float rgb[3];
+    const uint64_t dmask = __ballot(drawn);
+    if (dmask == 0) return;                       // wave-uniform
+    const int i0 = i - lane;                      // first Gaussian of this wave
+    // rows of culled Gaussians are not written: float4 m of the wave's chunk belongs to Gaussian m / 3
+    const auto write_rows = [&](float4* __restrict__ dst) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int m = r * 64 + lane;
+            const int gi = m / 3;
+            if ((dmask >> gi) & 1ull) dst[3 * (size_t)i0 + m] = st[m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if (drawn) {
     if (colors_precomp) {
         rgb[0] = colors_precomp[3 * (size_t)i];
         rgb[1] = colors_precomp[3 * (size_t)i + 1];
@@ -279,39 +345,38 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
         sh_basis<DEG>(dx, dy, dz, b);
         uint32_t pass = 0;
+        float v[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {     // per channel the same chain as a loop over k inside a loop over c
+#pragma clang fp contract(off)             // one rounding sequence in every instantiation: see sh_basis
+            v[0] += b[k] * sh[3 * k];
+            v[1] += b[k] * sh[3 * k + 1];
+            v[2] += b[k] * sh[3 * k + 2];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-#pragma clang fp contract(off)     // one rounding sequence in every instantiation: see sh_basis
-            float v = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NB; ++k) v += b[k] * sh[3 * k + c];
-            v += 0.5f;
-            rgb[c] = fminf(fmaxf(v, 0.0f), 1.0f);
-            if (v >= 0.0f && v <= 1.0f) pass |= 1u << c;
+            const float vc = v[c] + 0.5f;
+            rgb[c] = fminf(fmaxf(vc, 0.0f), 1.0f);
+            if (vc >= 0.0f && vc <= 1.0f) pass |= 1u << c;
         }
         if (JAC) {
-            float bg[NB][3];
-            sh_basis_grad<DEG>(dx, dy, dz, bg);
-            float Wm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int f = 0; f < NB * 3; ++f) {
-                const int k = f / 3, c = f % 3;
-                Wm[0][c] += bg[k][0] * sh[f];
-                Wm[1][c] += bg[k][1] * sh[f];
-                Wm[2][c] += bg[k][2] * sh[f];
-            }
-            float4* jp = sh_jac + 3 * (size_t)i;
-            jp[0] = make_float4(Wm[0][0], Wm[0][1], Wm[0][2], Wm[1][0]);
-            jp[1] = make_float4(Wm[1][1], Wm[1][2], Wm[2][0], Wm[2][1]);
-            jp[2] = make_float4(Wm[2][2], __uint_as_float(pass), 0.0f, 0.0f);
+            float Wm[3][3];
+            sh_dir_jacobian<DEG>(dx, dy, dz, sh, Wm);
+            st[3 * lane] = make_float4(Wm[0][0], Wm[0][1], Wm[0][2], Wm[1][0]);
+            st[3 * lane + 1] = make_float4(Wm[1][1], Wm[1][2], Wm[2][0], Wm[2][1]);
+            st[3 * lane + 2] = make_float4(Wm[2][2], __uint_as_float(pass), 0.0f, 0.0f);
         }
     }
-    const uint32_t rx = (uint32_t)g.xmin | ((uint32_t)g.xmax << 16);
-    const uint32_t ry = (uint32_t)g.ymin | ((uint32_t)g.ymax << 16);
-    float4* o = splat + 3 * (size_t)i;
-    o[0] = make_float4(g.mx, g.my, g.ca, g.cb);
-    o[1] = make_float4(g.cd, opacities[i], g.cam[2], __uint_as_float(rx));
-    o[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(ry));
+    }
+    if (JAC) write_rows(sh_jac);
+    if (drawn) {
+        const uint32_t rx = (uint32_t)g.xmin | ((uint32_t)g.xmax << 16);
+        const uint32_t ry = (uint32_t)g.ymin | ((uint32_t)g.ymax << 16);
+        st[3 * lane] = make_float4(g.mx, g.my, g.ca, g.cb);
+        st[3 * lane + 1] = make_float4(g.cd, opacities[i], g.cam[2], __uint_as_float(rx));
+        st[3 * lane + 2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(ry));
+    }
+    write_rows(splat);
 }
 
 // MODE 0: scalar SH access; 1: 16-byte SH loads/stores per lane (rows 16-byte aligned);

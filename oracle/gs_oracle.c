@@ -42,6 +42,20 @@
 #include <omp.h>
 #endif
 
+typedef float gso_f32; /* the 32-bit float behind the depth key, whatever `float` means below */
+#ifdef GSO_REAL_DOUBLE
+/*
+ * Arbiter build (libgs_oracle_f64.so, oracle/oracle64.py): the same source with every float -- arithmetic and
+ * interface arrays alike -- a double.  The f-suffixed constants keep their float values, so this is the SAME function
+ * of the same inputs evaluated (nearly) exactly: what the fp32 arithmetic above is an approximation of.  Used by the
+ * randomised parity test to tell an ill-conditioned case (the fp32 oracle itself is far from this) from a wrong result.
+ */
+#define float double
+#define sqrtf sqrt
+#define expf exp
+#define ceilf ceil
+#endif
+
 #define TILE 16
 #define BAND 8
 
@@ -165,8 +179,9 @@ static void cov3d_of(const float *scales, const float *rots, const float *cov6, 
 /* depth -> 32-bit key whose ascending order is descending depth (ties keep index order) */
 static uint32_t depth_key_desc(float z) {
     uint32_t u;
-    z = z + 0.0f; /* -0 -> +0 so that equal depths give equal keys */
-    memcpy(&u, &z, 4);
+    gso_f32 zf = (gso_f32)z;
+    zf = zf + 0.0f; /* -0 -> +0 so that equal depths give equal keys */
+    memcpy(&u, &zf, 4);
     uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ~asc;
 }

@@ -12,7 +12,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgs_oracle.so")
+# oracle64.py runs this file a second time with GSO_DOUBLE set: the float64 build of the same C source
+_DOUBLE = bool(globals().get("GSO_DOUBLE", False))
+REAL = np.float64 if _DOUBLE else np.float32
+_LIB_NAME = "libgs_oracle_f64.so" if _DOUBLE else "libgs_oracle.so"
+_LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 _lib = None
 
 TILE = 16
@@ -21,7 +25,7 @@ TILE = 16
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "gs_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libgs_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", _LIB_NAME], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -40,7 +44,7 @@ def _p(a):
 
 
 def _f32(a):
-    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    return None if a is None else np.ascontiguousarray(a, dtype=REAL)
 
 
 def set_threads(n: int):
@@ -68,11 +72,11 @@ def preprocess(H, W, sh_degree, viewmatrix, projmatrix, campos, means3D, scales=
     g.view, g.proj, g.campos = _f32(viewmatrix).reshape(16), _f32(projmatrix).reshape(16), _f32(campos)
     g.means3D, g.scales, g.rotations, g.cov6, g.shs, g.colors_precomp = (
         means3D, scales, rotations, cov3D_precomp, shs, colors_precomp)
-    g.xy = np.zeros((N, 2), np.float32)
-    g.depth = np.zeros(N, np.float32)
-    g.cov2d = np.zeros((N, 3), np.float32)
-    g.conic = np.zeros((N, 3), np.float32)
-    g.rgb = np.zeros((N, 3), np.float32)
+    g.xy = np.zeros((N, 2), REAL)
+    g.depth = np.zeros(N, REAL)
+    g.cov2d = np.zeros((N, 3), REAL)
+    g.conic = np.zeros((N, 3), REAL)
+    g.rgb = np.zeros((N, 3), REAL)
     g.rect = np.zeros((N, 4), np.int32)
     g.radii = np.zeros(N, np.int32)
     g.tiles_touched = np.zeros(N, np.uint32)
@@ -109,9 +113,9 @@ def binning(g: Geom):
 def render_forward(g: Geom, opacities, bg):
     op = _f32(opacities).reshape(-1)
     bg = _f32(bg)
-    img = np.zeros((3, g.H, g.W), np.float32)
-    dep = np.zeros((1, g.H, g.W), np.float32)
-    alp = np.zeros((1, g.H, g.W), np.float32)
+    img = np.zeros((3, g.H, g.W), REAL)
+    dep = np.zeros((1, g.H, g.W), REAL)
+    alp = np.zeros((1, g.H, g.W), REAL)
     rc = lib().gso_render_forward(g.N, g.H, g.W, _p(bg), _p(g.xy), _p(g.depth), _p(g.conic), _p(g.rgb),
                                   _p(op), _p(g.rect), _p(g.tiles_touched), _p(img), _p(dep), _p(alp))
     assert rc == 0
@@ -121,11 +125,11 @@ def render_forward(g: Geom, opacities, bg):
 def render_backward(g: Geom, opacities, G_C, G_Z=None, G_A=None):
     op = _f32(opacities).reshape(-1)
     G_C = _f32(G_C)
-    G_Z = np.zeros((1, g.H, g.W), np.float32) if G_Z is None else _f32(G_Z)
-    G_A = np.zeros((1, g.H, g.W), np.float32) if G_A is None else _f32(G_A)
-    out = dict(d_xy=np.zeros((g.N, 2), np.float32), d_conic=np.zeros((g.N, 3), np.float32),
-               d_rgb=np.zeros((g.N, 3), np.float32), d_opacity=np.zeros((g.N, 1), np.float32),
-               d_depth=np.zeros(g.N, np.float32))
+    G_Z = np.zeros((1, g.H, g.W), REAL) if G_Z is None else _f32(G_Z)
+    G_A = np.zeros((1, g.H, g.W), REAL) if G_A is None else _f32(G_A)
+    out = dict(d_xy=np.zeros((g.N, 2), REAL), d_conic=np.zeros((g.N, 3), REAL),
+               d_rgb=np.zeros((g.N, 3), REAL), d_opacity=np.zeros((g.N, 1), REAL),
+               d_depth=np.zeros(g.N, REAL))
     rc = lib().gso_render_backward(g.N, g.H, g.W, _p(g.xy), _p(g.depth), _p(g.conic), _p(g.rgb), _p(op),
                                    _p(g.rect), _p(g.tiles_touched), _p(G_C), _p(G_Z), _p(G_A),
                                    _p(out["d_xy"]), _p(out["d_conic"]), _p(out["d_rgb"]),
@@ -136,12 +140,12 @@ def render_backward(g: Geom, opacities, G_C, G_Z=None, G_A=None):
 
 def preprocess_backward(g: Geom, rb: dict):
     N, K = g.N, g.K
-    res = dict(means3D=np.zeros((N, 3), np.float32))
-    res["scales"] = np.zeros((N, 3), np.float32) if g.scales is not None and g.cov6 is None else None
-    res["rotations"] = np.zeros((N, 4), np.float32) if g.rotations is not None and g.cov6 is None else None
-    res["cov3D_precomp"] = np.zeros((N, 6), np.float32) if g.cov6 is not None else None
-    res["shs"] = np.zeros((N, K, 3), np.float32) if g.shs is not None else None
-    res["colors_precomp"] = np.zeros((N, 3), np.float32) if g.colors_precomp is not None else None
+    res = dict(means3D=np.zeros((N, 3), REAL))
+    res["scales"] = np.zeros((N, 3), REAL) if g.scales is not None and g.cov6 is None else None
+    res["rotations"] = np.zeros((N, 4), REAL) if g.rotations is not None and g.cov6 is None else None
+    res["cov3D_precomp"] = np.zeros((N, 6), REAL) if g.cov6 is not None else None
+    res["shs"] = np.zeros((N, K, 3), REAL) if g.shs is not None else None
+    res["colors_precomp"] = np.zeros((N, 3), REAL) if g.colors_precomp is not None else None
     rc = lib().gso_preprocess_backward(
         N, K, g.deg, g.H, g.W, _p(g.view), _p(g.proj), _p(g.campos), _p(g.means3D), _p(g.scales),
         _p(g.rotations), _p(g.cov6), _p(g.shs), _p(g.tiles_touched), _p(g.clampmask), _p(g.cov2d),

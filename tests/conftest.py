@@ -20,6 +20,14 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle64():
+    """The same oracle built in float64 (oracle/oracle64.py): arbiter for ill-conditioned randomised cases."""
+    from oracle import oracle64 as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
 def oracle_adam():
     from oracle import adam_oracle
     return adam_oracle

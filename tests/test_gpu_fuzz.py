@@ -2,7 +2,15 @@
 cameras, Gaussians behind / on top of the camera, screen-filling, needle-thin, nearly opaque, unnormalised
 quaternions; SH or precomputed colours, scales+rotations or precomputed covariances) against the CPU oracle in exact
 mode (t_eps = 0): radii bit-exact, image / alpha / depth and every gradient at the tolerances of tests/util.py --
-the gradient bar is the stated 1e-3 * max|grad| per tensor, no exceptions.
+the gradient bar is the stated 1e-3 * max|grad| per tensor, no exceptions and no wider bar for any seed.
+
+What the bar is measured against: the fp32 oracle.  Some of these scenes are ill-conditioned in fp32 itself -- a splat of
+radius 30 000 px with a nearly singular 2x2 covariance on a 1-pixel-wide frame: the fp32 ORACLE is then 1.5e-3 * max|grad|
+away from the float64 evaluation of its own formulas (seed 71, d_rotations), so which side of 1e-3 a correct fp32 result
+lands on is decided by which instructions the compiler happened to fuse.  For a tensor that misses the bar against the
+fp32 oracle, the float64 build of the same oracle (oracle/oracle64.py) arbitrates, and only if the fp32 oracle is itself
+further than a quarter of the bar from it and both took the same discrete decisions (boxes, radii): the HIP gradient
+must then be within the SAME 1e-3 * max|grad| of the float64 evaluation.  A well-conditioned miss stays a failure.
 
 Two things keep these scenes inside it ("Randomised hunt"): the backward takes the part of a
 pixel's sum that lies behind a Gaussian as 0, not as total - prefix, once the pixel's transmittance has reached its stop
@@ -23,16 +31,21 @@ GRAD_REL = 1e-3
 WIDER = {}
 
 
-def test_fuzz_200_adversarial_scenes_vs_oracle(oracle):
+def test_fuzz_200_adversarial_scenes_vs_oracle(oracle, oracle64):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import diff_gaussian_rasterization as dgr
     import fuzz_parity as F
-    failures = []
+    failures, arbitrated = [], {}
     for seed in range(200):
         case = F.make_case(seed)
+        arb = []
         try:
-            F.run_case(case, dgr, oracle, t_eps=0.0, grad_rel=WIDER.get(seed, GRAD_REL))
+            F.run_case(case, dgr, oracle, t_eps=0.0, grad_rel=WIDER.get(seed, GRAD_REL), oracle64=oracle64, arbitrated=arb)
         except AssertionError as e:
             failures.append(f"seed {seed} (N={case['N']} {case['W']}x{case['H']} K={case['K']} deg={case['deg']}): {e}")
+        if arb:
+            arbitrated[seed] = arb
+    print(f"decided by the float64 arbiter: {arbitrated}")
     assert not failures, "\n".join(failures)
+    assert len(arbitrated) <= 4, f"the arbiter is for the odd ill-conditioned scene, not for {len(arbitrated)} of 200"

@@ -12,12 +12,17 @@ import fuzz_parity as F  # noqa: E402
 
 def main():
     import diff_gaussian_rasterization as dgr
-    from oracle import oracle
+    from oracle import oracle, oracle64
     oracle.build()
+    oracle64.build()
     dev = torch.device("cuda:0")
     for seed in map(int, sys.argv[1:]):
         c = F.make_case(seed)
         outs, grads, geom = oracle.forward_backward(
+            c["H"], c["W"], c["deg"], c["viewmatrix"], c["projmatrix"], c["campos"], c["bg"], c["means3D"],
+            c["opacities"], scales=c["scales"], rotations=c["rotations"], cov3D_precomp=c["cov3D_precomp"],
+            shs=c["shs"], colors_precomp=c["colors_precomp"], G_C=c["G_C"], G_Z=c["G_Z"], G_A=c["G_A"])
+        _, grads64, geom64 = oracle64.forward_backward(
             c["H"], c["W"], c["deg"], c["viewmatrix"], c["projmatrix"], c["campos"], c["bg"], c["means3D"],
             c["opacities"], scales=c["scales"], rotations=c["rotations"], cov3D_precomp=c["cov3D_precomp"],
             shs=c["shs"], colors_precomp=c["colors_precomp"], G_C=c["G_C"], G_Z=c["G_Z"], G_A=c["G_A"])
@@ -36,15 +41,22 @@ def main():
         print(f"== seed {seed}: N={c['N']} {c['W']}x{c['H']} drawn {(geom.radii > 0).sum()} pairs {geom.tiles_touched.sum()}")
         print("   image err", np.abs(image.detach().cpu().numpy() - outs["render"]).max(),
               "alpha err", np.abs(alpha.detach().cpu().numpy() - outs["alpha"]).max())
+        print("   boxes of the float64 evaluation equal:", np.array_equal(geom.rect, geom64.rect))
+        ms = m2.grad.cpu().numpy()[:, :2] / np.array([0.5 * c["W"], 0.5 * c["H"]], np.float32)
+        e32, e64 = np.abs(ms - grads["means_screen"]).max(), np.abs(ms - grads64["means_screen"]).max()
+        print(f"   d_means_screen: max|ref| {np.abs(grads64['means_screen']).max():.3e} hip-oracle32 {e32:.3e} hip-oracle64 {e64:.3e} "
+              f"oracle32-oracle64 {np.abs(grads['means_screen'] - grads64['means_screen']).max():.3e}")
         for k in F.INPUTS:
             if inp[k] is None:
                 continue
             got, ref = inp[k].grad.cpu().numpy().reshape(c["N"], -1), grads[k].reshape(c["N"], -1)
+            ref64 = grads64[k].reshape(c["N"], -1)
             err = np.abs(got - ref)
-            print(f"   d_{k}: max|ref| {np.abs(ref).max():.3e} max err {err.max():.3e}")
+            print(f"   d_{k}: max|ref| {np.abs(ref).max():.3e} max err {err.max():.3e} | vs float64: hip {np.abs(got - ref64).max():.3e} "
+                  f"oracle32 {np.abs(ref - ref64).max():.3e}")
             for i in np.argsort(-err.max(axis=1))[:3]:
                 j = int(err[i].argmax())
-                print(f"      gaussian {i} comp {j}: hip {got[i, j]:+.6e} oracle {ref[i, j]:+.6e} | radius {geom.radii[i]} "
+                print(f"      gaussian {i} comp {j}: hip {got[i, j]:+.6e} oracle {ref[i, j]:+.6e} f64 {ref64[i, j]:+.6e} | radius {geom.radii[i]} "
                       f"depth {geom.depth[i]:.3f} opacity {c['opacities'][i, 0]:.4f} conic {geom.conic[i]} rect {geom.rect[i]}")
 
 

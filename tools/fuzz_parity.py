@@ -84,15 +84,32 @@ def make_case(seed):
 INPUTS = ("means3D", "opacities", "scales", "rotations", "cov3D_precomp", "shs", "colors_precomp")
 
 
-def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None):
-    """Raises AssertionError on a mismatch; returns the worst relative gradient error."""
+# A gradient tensor whose fp32 oracle value is itself further than this fraction of the bar from the float64 evaluation of
+# the same formulas is ill-conditioned in fp32: the float64 evaluation then arbitrates, at the same bar.
+ARBITER_NOISE_FRAC = 0.25
+
+
+def _oracle_call(orc, case):
+    return orc.forward_backward(
+        case["H"], case["W"], case["deg"], case["viewmatrix"], case["projmatrix"], case["campos"], case["bg"],
+        case["means3D"], case["opacities"], scales=case["scales"], rotations=case["rotations"],
+        cov3D_precomp=case["cov3D_precomp"], shs=case["shs"], colors_precomp=case["colors_precomp"], G_C=case["G_C"],
+        G_Z=case["G_Z"], G_A=case["G_A"])
+
+
+def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None, oracle64=None, arbitrated=None):
+    """Raises AssertionError on a mismatch; returns the worst relative gradient error.
+
+    The bar for every gradient tensor is grad_rel * max|grad| against the fp32 oracle.  oracle64 (optional: the float64
+    build of the same oracle) arbitrates the tensors that miss it: if the fp32 oracle's own distance from the float64
+    evaluation exceeds ARBITER_NOISE_FRAC of the bar (the scene is ill-conditioned in fp32: the reference arithmetic
+    itself does not pin the value to the bar) and both evaluations took the same discrete decisions (boxes, radii),
+    the HIP result must be within the SAME bar of the float64 evaluation instead.  `arbitrated` (a list) collects the
+    names of tensors decided that way."""
     from util import TOL_DEPTH, TOL_GRAD_REL, TOL_IMAGE, check_grad
     dev = torch.device("cuda:0")
     H, W = case["H"], case["W"]
-    outs, grads, geom = oracle.forward_backward(
-        H, W, case["deg"], case["viewmatrix"], case["projmatrix"], case["campos"], case["bg"], case["means3D"],
-        case["opacities"], scales=case["scales"], rotations=case["rotations"], cov3D_precomp=case["cov3D_precomp"],
-        shs=case["shs"], colors_precomp=case["colors_precomp"], G_C=case["G_C"], G_Z=case["G_Z"], G_A=case["G_A"])
+    outs, grads, geom = _oracle_call(oracle, case)
     t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
     inp = {k: (None if case[k] is None else t(case[k]).requires_grad_(True)) for k in INPUTS}
     settings = dgr.GaussianRasterizationSettings(
@@ -115,11 +132,30 @@ def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None):
         err = np.abs(got - ref).max()
         assert err <= tol, f"{name}: max-abs err {err:.3e} > {tol}"
     worst = 0.0
+    rel = grad_rel or TOL_GRAD_REL
+    exact = None
     for k in INPUTS:
         if inp[k] is not None:
             assert np.isfinite(grads[k]).all(), f"oracle gradient of {k} is not finite: not a usable case"
-            worst = max(worst, check_grad(f"d_{k}", inp[k].grad.cpu().numpy(), grads[k],
-                                              rel=grad_rel or TOL_GRAD_REL))
+            got = inp[k].grad.cpu().numpy()
+            try:
+                worst = max(worst, check_grad(f"d_{k}", got, grads[k], rel=rel))
+            except AssertionError:
+                if oracle64 is None:
+                    raise
+                if exact is None:
+                    _, g64, geom64 = _oracle_call(oracle64, case)
+                    same = np.array_equal(geom64.rect, geom.rect) and np.array_equal(geom64.radii, geom.radii)
+                    exact = (g64, same)
+                g64, same = exact
+                ref64 = np.asarray(g64[k], dtype=np.float64)
+                noise = np.abs(np.asarray(grads[k], dtype=np.float64) - ref64).max()
+                if not same or noise <= ARBITER_NOISE_FRAC * rel * np.abs(ref64).max():
+                    raise       # the fp32 oracle is well-conditioned here: its verdict stands
+                worst = max(worst, check_grad(f"d_{k} (vs the float64 evaluation; fp32 oracle off by {noise:.2e})",
+                                              got, ref64, rel=rel))
+                if arbitrated is not None:
+                    arbitrated.append(k)
     return worst
 
 
@@ -128,16 +164,18 @@ def main():
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     t_eps = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     import diff_gaussian_rasterization as dgr
-    from oracle import oracle
+    from oracle import oracle, oracle64
     oracle.build()
+    oracle64.build()
     bad = 0
     for seed in range(first, first + cases):
         case = make_case(seed)
         tag = (f"seed {seed}: N={case['N']} {case['W']}x{case['H']} K={case['K']} deg={case['deg']} "
                f"{'cov' if case['cov3D_precomp'] is not None else 'sr'}/{'rgb' if case['colors_precomp'] is not None else 'sh'}")
         try:
-            worst = run_case(case, dgr, oracle, t_eps)
-            print(f"ok   {tag} worst grad err {worst:.2e}", flush=True)
+            arb = []
+            worst = run_case(case, dgr, oracle, t_eps, oracle64=oracle64, arbitrated=arb)
+            print(f"ok   {tag} worst grad err {worst:.2e}" + (f" (float64 arbiter: {', '.join(arb)})" if arb else ""), flush=True)
         except AssertionError as e:
             bad += 1
             print(f"FAIL {tag}: {e}", flush=True)

@@ -162,6 +162,35 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t* squ = (const uint32_t*)sq;
     int cnt[GS_ROWS] = {0, 0, 0, 0};
+    if (BATCH <= 32) {
+        // A batch of at most 32 pairs would leave half the wave idle in the loop below: here lane (j, h) tests pair j =
+        // lane & 31 against the block rows h = lane >> 5 selects (h = 0: the sub-tile's upper two 4x4 blocks, h = 1: the
+        // lower two), so one ballot carries two lists -- bits 0..31 the upper block's, bits 32..63 the lower block's --
+        // and the four lists take two ballots, two list stores and two position stores instead of four of each.
+        const int j = lane & 31, h = lane >> 5;
+        bool hx0 = false, hx1 = false, hy = false;
+        if (j < n) {
+            const uint32_t lo = squ[12 * j + 6], hi = squ[12 * j + 7];
+            const int xmin = lo & 0xFFFF, ymin = lo >> 16, xlast = hi & 0xFFFF, ylast = hi >> 16;
+            const int y0 = c.sy0 + h * GS_QUAD;
+            hx0 = xmin < c.sx0 + GS_QUAD && xlast >= c.sx0;
+            hx1 = xmin < c.sx0 + 2 * GS_QUAD && xlast >= c.sx0 + GS_QUAD;
+            hy = ymin < y0 + GS_QUAD && ylast >= y0;
+        }
+        const uint32_t lt32 = (1u << j) - 1u;
+#pragma unroll
+        for (int xq = 0; xq < 2; ++xq) {
+            const bool hit = (xq ? hx1 : hx0) && hy;
+            const uint64_t m = __ballot(hit);
+            const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+            const int q = 2 * h + xq;                              // this lane's row: make_ctx's row = 2 (y half) + (x half)
+            const int pos = __popc((h ? mhi : mlo) & lt32);
+            if (hit) wl[q * (BATCH + 1) + pos] = 48u * (uint32_t)j;
+            if (posmap && j < BATCH) posmap[q * BATCH + j] = hit ? (uint16_t)pos : (uint16_t)0xFFFF;
+            cnt[xq] = __popc(mlo);
+            cnt[2 + xq] = __popc(mhi);
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < (BATCH + 63) / 64; ++r) {
         const int j = r * 64 + lane;
@@ -183,6 +212,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
             if (posmap && j < BATCH) posmap[q * BATCH + j] = hit[q] ? (uint16_t)pos : (uint16_t)0xFFFF;
             cnt[q] += __popcll(m);
         }
+    }
     }
     const int nmax = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
 #pragma unroll

@@ -208,10 +208,15 @@ class _RasterizeSharded(torch.autograd.Function):
             dkeys_s = torch.empty((world, max(n, 1)), **i32)[:, :n]
             rects_s = torch.empty((world, max(n, 1), 2), **i32)[:, :n]
             ids_scratch = torch.empty((max(n, 1),), **i32)[:n]
+            # the colour side table of my shard in every view stays here, for the per-view chain rule of the backward
+            jac = None
+            if need_grad and R.USE_SH_JAC and shs is not None and n > 0:
+                jac = torch.empty((world, n, R.sh_jac_row_floats()), dtype=torch.float32, device=dev)
             radii = []
             for v in range(world):
                 _, r, _, _, _, _ = R.preprocess(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                                colors_precomp, out=(splat_s[v], dkeys_s[v], ids_scratch, rects_s[v]))
+                                                colors_precomp, out=(splat_s[v], dkeys_s[v], ids_scratch, rects_s[v]),
+                                                sh_jac=None if jac is None else jac[v])
                 radii.append(r)
             radii = torch.stack(radii) if world else torch.empty((0, n), **i32)
             # 2. records, depth keys and boxes of ALL Gaussians for MY view, in global index order
@@ -237,6 +242,7 @@ class _RasterizeSharded(torch.autograd.Function):
             image, depth, alpha, aux, rows = R.render_forward(mine, splat, state.ranges, state.point_list, need_grad,
                                                               t_eps, band)
         ctx.rows = rows
+        ctx.sh_jac = jac
         ctx.set_materialize_grads(False)
         ctx.views, ctx.t_eps, ctx.counts, ctx.group, ctx.band = views, float(t_eps), list(counts), group, band
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
@@ -290,7 +296,8 @@ class _RasterizeSharded(torch.autograd.Function):
                     w_rows = None
                 g = R.preprocess_backward(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
                                           colors_precomp, radii[v], rows[off:off + n] if v == rank else rows_mine[v], needs,
-                                          (n, 3) if per_view_means2D else None, accumulate_into=acc)
+                                          (n, 3) if per_view_means2D else None, accumulate_into=acc,
+                                          sh_jac=None if ctx.sh_jac is None else ctx.sh_jac[v])
                 if per_view_means2D and needs[1]:
                     g_m2d[v] = g[1]
                 acc = g

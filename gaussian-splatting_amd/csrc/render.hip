@@ -140,11 +140,13 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
 // shorter than the longest are padded with the offset of a record no lane is ever inside
 // (sq[BATCH]), so the per-visit loop needs no "is my list exhausted" test.  wl = this wave's lists,
 // GS_ROWS x (BATCH + 1) entries (one spare for the loop's prefetch); posmap (optional, GS_ROWS x BATCH, u16) = position of pair j in each list,
-// 0xFFFF when it is not in it.  Returns the length of the longest list.
+// 0xFFFF when it is not in it.  dead_rows: bit q set = every pixel of row q's block has stopped (or lies outside the image):
+// its list stays empty, so it neither lengthens the wave's walk nor costs skipped visits.  Returns the length of the
+// longest list.
 template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
-                                              uint32_t* wl, uint16_t* posmap) {
+                                              uint32_t* wl, uint16_t* posmap, uint32_t dead_rows) {
     static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
     if (tid < n && tid < BATCH) {
@@ -180,10 +182,10 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         const uint32_t lt32 = (1u << j) - 1u;
 #pragma unroll
         for (int xq = 0; xq < 2; ++xq) {
-            const bool hit = (xq ? hx1 : hx0) && hy;
+            const int q = 2 * h + xq;                              // this lane's row: make_ctx's row = 2 (y half) + (x half)
+            const bool hit = (xq ? hx1 : hx0) && hy && !((dead_rows >> q) & 1u);
             const uint64_t m = __ballot(hit);
             const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
-            const int q = 2 * h + xq;                              // this lane's row: make_ctx's row = 2 (y half) + (x half)
             const int pos = __popc((h ? mhi : mlo) & lt32);
             if (hit) wl[q * (BATCH + 1) + pos] = 48u * (uint32_t)j;
             if (posmap && j < BATCH) posmap[q * BATCH + j] = hit ? (uint16_t)pos : (uint16_t)0xFFFF;
@@ -203,7 +205,8 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
             hy0 = ymin < c.sy0 + GS_QUAD && ylast >= c.sy0;
             hy1 = ymin < c.sy0 + 2 * GS_QUAD && ylast >= c.sy0 + GS_QUAD;
         }
-        const bool hit[GS_ROWS] = {hx0 && hy0, hx1 && hy0, hx0 && hy1, hx1 && hy1};
+        const bool hit[GS_ROWS] = {hx0 && hy0 && !(dead_rows & 1u), hx1 && hy0 && !(dead_rows & 2u),
+                                   hx0 && hy1 && !(dead_rows & 4u), hx1 && hy1 && !(dead_rows & 8u)};
 #pragma unroll
         for (int q = 0; q < GS_ROWS; ++q) {
             const uint64_t m = __ballot(hit[q]);
@@ -221,6 +224,15 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return __builtin_amdgcn_readfirstlane(nmax);      // wave-uniform: keep the visit loop's bound in an SGPR
+}
+
+// bit q: all 16 lanes of DPP row q of this wave have stopped (wave-uniform)
+__device__ __forceinline__ uint32_t dead_row_mask(uint32_t P) {
+    const uint64_t st = __ballot(P == P_STOPPED);
+    uint32_t d = 0;
+#pragma unroll
+    for (int q = 0; q < GS_ROWS; ++q) d |= (((st >> (16 * q)) & 0xFFFFull) == 0xFFFFull) ? (1u << q) : 0u;
+    return d;
 }
 
 __device__ __forceinline__ void write_pad_record(f4* sq, int BATCH) {
@@ -264,7 +276,8 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
-        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr);
+        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr,
+                                               dead_row_mask(P));
         uint32_t off_next = mylist[0];   // list entry one visit ahead: one LDS latency per visit, not two
         for (int kk = 0; kk < nmax; ++kk) {
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
@@ -526,7 +539,8 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
         if (__syncthreads_and(P == P_STOPPED)) break;
         const int n = min((int)(range.y - base), BATCH);
-        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave]);
+        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
+                                               dead_row_mask(P));
         uint64_t visited = 0;
         uint32_t off_next = mylist[0];
         for (int kk = 0; kk < nmax; ++kk) {

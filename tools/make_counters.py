@@ -36,10 +36,27 @@ STAGE = {"render_bwd": ["render_bwd_kernel"], "render_fwd": ["render_fwd_kernel"
          "radix_sort_pass": ["radix_hist_kernel", "radix_scatter_kernel"]}
 # mean issue cost of the visit loops' instruction mix (profiles/r1f_valu_issue_rates.txt; counted in the ISA)
 ISSUE = {"render_bwd": float(os.environ.get("GS_BWD_ISSUE_CYCLES", "3.67")), "render_fwd": 3.57}
+# Several instantiations of one kernel can appear in a trace (the bench also renders once without a backward to follow:
+# preprocess_fwd_kernel<3, true, false>).  A stage counts each kernel name once: the instantiation the timed path
+# launches, i.e. the one with the most calls in the kernel trace.
+calls = {}
+stats_csv = os.path.join(out, f"{tag}_kernel_stats.csv")
+if os.path.exists(stats_csv):
+    for r in csv.DictReader(open(stats_csv)):
+        m = re.search(r"::(\w+_kernel)(<.*?>)?\(", r["Name"])
+        if m:
+            calls[m.group(1) + (m.group(2) or "")] = int(r["Calls"])
+best = {}
+for name in vals:
+    base = name.split("<")[0]
+    if base not in best or calls.get(name, 0) > calls.get(best[base], 0):
+        best[base] = name
 kernels = {}
 for stage, prefixes in STAGE.items():
     acc = {}
     for name, d in vals.items():
+        if best.get(name.split("<")[0]) != name:
+            continue
         if any(name.startswith(p) for p in prefixes):
             for k, v in d.items():
                 acc[k] = acc.get(k, 0.0) + v

@@ -54,14 +54,14 @@ int gs_grad_row_floats(void);    /* 16: floats (4-byte units) per per-Gaussian g
  * 0 .. ceil(H/16)); tiles_touched counts only tiles inside the band (tile-row sharded inference,
  * BASELINE.json config 5); radii are independent of the band.
  * Outputs: splat (N x 12 floats, 48-byte records, layout in csrc/gsplat_common.h; rows of culled
- * Gaussians are not written), radii (N) int32 = ceil(3 sigma_max) or 0 when not drawn,
+ * Gaussians are zero), radii (N) int32 = ceil(3 sigma_max) or 0 when not drawn,
  * tiles_touched (N) = number of 16x16 tiles the integer box overlaps.  depth_keys / ids (N each) /
  * rects (N x 2 uint32: x_min | x_max << 16, y_min | y_max << 16; all zero when not drawn), all three
  * or none NULL: input of the binning stage, depth_keys[i] = 32-bit key whose
  * ascending order is descending depth (0xFFFFFFFF for Gaussians that are not drawn, so they sort last), ids[i] = i.
  * sh_jac (optional, NULL = not wanted; only with shs; 16-byte aligned): side table for gs_preprocess_bwd, one row of
- * gs_sh_jac_row_floats() = 12 floats (48 bytes) per Gaussian (rows of Gaussians that are not drawn are left
- * unwritten): floats 0..8 = d colour_c / d dir_a = sum_k (d basis_k / d dir_a) sh_kc at index 3 a + c (the
+ * gs_sh_jac_row_floats() = 12 floats (48 bytes) per Gaussian (zeros for Gaussians that are not
+ * drawn): floats 0..8 = d colour_c / d dir_a = sum_k (d basis_k / d dir_a) sh_kc at index 3 a + c (the
  * view-direction Jacobian autograd forms from utils/sh_utils.py:40-96), word 9 = bit c set when channel c was inside
  * the clamp of gaussian_renderer/__init__.py:206, words 10..11 unused.  With it the backward does not read the
  * N x K x 3 coefficients a second time.

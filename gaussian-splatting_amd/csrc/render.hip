@@ -43,6 +43,17 @@
 // gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
 #include "gsplat_common.h"
 
+// -DGS_STATS (tools/build_variant.sh stats -DGS_STATS, read with tools/bwd_stats.py): utilisation counters of the backward
+// kernel -- batches, list lengths, executed visits, active lanes, live rows, flush rounds.  Not in the product build.
+#ifdef GS_STATS
+__device__ unsigned long long gs_dbg[16];
+extern "C" int gs_dbg_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gs_dbg), sizeof(gs_dbg)); }
+extern "C" int gs_dbg_clear() { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(gs_dbg), z, sizeof(z)); }
+#define GS_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gs_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define GS_STAT(i, v) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -543,12 +554,21 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                                                dead_row_mask(P));
         uint64_t visited = 0;
         uint32_t off_next = mylist[0];
+        GS_STAT(0, 1); GS_STAT(1, nmax); GS_STAT(8, n);
         for (int kk = 0; kk < nmax; ++kk) {
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
+            GS_STAT(2, 1);
             const Rec rec = load_rec(sq, off_next);
             off_next = mylist[kk + 1];
             const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
             if (!__any(act)) continue;
+#ifdef GS_STATS
+            {
+                const uint64_t am = __ballot(act);
+                GS_STAT(3, 1); GS_STAT(4, __popcll(am));
+                GS_STAT(5, ((am & 0xFFFFull) != 0) + (((am >> 16) & 0xFFFFull) != 0) + (((am >> 32) & 0xFFFFull) != 0) + ((am >> 48) != 0));
+            }
+#endif
             visited |= 1ull << kk;
             const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
             const float power2 = gauss_power2(rec, dx, dy);
@@ -597,7 +617,9 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const uint32_t pos = blk_posmap[j];
             const bool valid = j < n && pos != 0xFFFFu && ((blk_visited >> pos) & 1ull);
             const uint64_t vm = __ballot(valid);
+            GS_STAT(6, 1); GS_STAT(9, __popcll(vm));
             if (vm == 0) continue;                   // wave-uniform: none of this wave's 4 pairs was visited
+            GS_STAT(7, 1);
             const bool any = ((vm >> (lane & 48)) & 0xFFFFull) != 0;
             // lanes without a slot read the always-zero slot behind the last one
             const float* sl = valid ? blk_slots + pos * SLOT : slots + NBLK * BSTR;

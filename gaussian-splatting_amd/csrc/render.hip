@@ -34,7 +34,8 @@
 // 4x4 block's own pixel coordinates (row_moments_and_totals: 8 DPP instructions) plus the totals of the four
 // colour / depth products (8 DPP adds) -- 16 half-rate instructions instead of the 22 a reduce-scatter of the ten
 // per-Gaussian sums needs, and the products with dx, dy are never formed.  Ten lanes of the row store one dword
-// each into the 40-byte LDS slot of (4x4 block, list position) -- plain stores; after the batch the 16 lanes of a
+// each into the 40-byte LDS slot of (4x4 block, list position) -- plain stores into a slot pool shared by the tile's 16
+// blocks, so that a 64-pair batch fits the LDS of 6 workgroups per CU; after the batch the 16 lanes of a
 // DPP row take one pair each, lane b reads block b's slot and moves its moments to the centre of the Gaussian's
 // box, a 22-add reduce-scatter adds the 16 blocks up, and one row-shaped atomic per (tile, Gaussian) goes into
 // that Gaussian's 64-byte gradient row (six geometric sums as fp64 atomics: gsplat_common.h).
@@ -69,9 +70,12 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #define GS_FWD_BATCH_DEF 128     // pairs per forward batch (64 and 256 measured: see DESIGN.md)
 #endif
 #ifndef GS_BWD_BATCH_DEF
-#define GS_BWD_BATCH_DEF 32
+#define GS_BWD_BATCH_DEF 64
 #endif
-constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch: 16 blocks x 32 slots x 40 B = 20 KB of LDS
+#ifndef GS_BWD_POOL
+#define GS_BWD_POOL 480     // slots of the backward's pool (0 = BATCH slots per block); measured 400..492: see render_bwd_kernel
+#endif
+constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch (at most 64: one visited bit per list position)
 
 // LDS form of a splat record (written by stage_and_cull):
 //   q0 = (mean_x, mean_y, A', B')   q1 = (C', opacity, x_min | y_min << 16, (x_max - 1) | (y_max - 1) << 16)
@@ -114,6 +118,11 @@ __device__ __forceinline__ bool in_box(uint32_t P, uint32_t lo, uint32_t hi) {
     return __builtin_bit_cast(uint32_t, c) == P;
 }
 
+// list entries are record byte offsets (48 j <= 48 x 256) and list positions are < 64: 16 and 8 bits, so that the lists and
+// the position maps leave the backward's LDS to its slot pool
+typedef uint16_t wl_t;
+typedef uint8_t pos_t;
+constexpr pos_t POS_NONE = 0xFF;
 constexpr uint32_t P_STOPPED = 0xFFFFFFFFu;   // never inside a box: x_max - 1 <= 65534
 // Box of the padding record that fills the shorter row lists: x test passes only for x = 0xFFFF
 // (stopped lanes), y test only for y = 0 (never a stopped lane) -> no lane is ever inside it.
@@ -150,17 +159,19 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
 // the byte offsets (48 j) of the records whose box overlaps that block, in list order.  Lists
 // shorter than the longest are padded with the offset of a record no lane is ever inside
 // (sq[BATCH]), so the per-visit loop needs no "is my list exhausted" test.  wl = this wave's lists,
-// GS_ROWS x (BATCH + 1) entries (one spare for the loop's prefetch); posmap (optional, GS_ROWS x BATCH, u16) = position of pair j in each list,
-// 0xFFFF when it is not in it.  dead_rows: bit q set = every pixel of row q's block has stopped (or lies outside the image):
-// its list stays empty, so it neither lengthens the wave's walk nor costs skipped visits.  Returns the length of the
-// longest list.
+// GS_ROWS x (BATCH + 1) entries (one spare for the loop's prefetch); posmap (optional, GS_ROWS x BATCH, u8) = position of pair j in each list,
+// POS_NONE when it is not in it.  dead_rows: bit q set = every pixel of row q's block has stopped (or lies outside the image):
+// its list stays empty, so it neither lengthens the wave's walk nor costs skipped visits.  cnt_out (optional) = the four
+// list lengths; load = false: the records are staged already (a batch culled again with a smaller n).  Returns the length
+// of the longest list.
 template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
-                                              uint32_t* wl, uint16_t* posmap, uint32_t dead_rows) {
+                                              wl_t* wl, pos_t* posmap, uint32_t dead_rows,
+                                              int* cnt_out = nullptr, bool load = true) {
     static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
-    if (tid < n && tid < BATCH) {
+    if (load && tid < n && tid < BATCH) {
         const uint32_t id = point_list[base + tid];
         const f4* p = splat + 3 * (size_t)id;
         f4 p0 = p[0], p1 = p[1], p2 = p[2];
@@ -198,8 +209,8 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
             const uint64_t m = __ballot(hit);
             const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
             const int pos = __popc((h ? mhi : mlo) & lt32);
-            if (hit) wl[q * (BATCH + 1) + pos] = 48u * (uint32_t)j;
-            if (posmap && j < BATCH) posmap[q * BATCH + j] = hit ? (uint16_t)pos : (uint16_t)0xFFFF;
+            if (hit) wl[q * (BATCH + 1) + pos] = (wl_t)(48u * (uint32_t)j);
+            if (posmap && j < BATCH) posmap[q * BATCH + j] = hit ? (pos_t)pos : POS_NONE;
             cnt[xq] = __popc(mlo);
             cnt[2 + xq] = __popc(mhi);
         }
@@ -222,16 +233,20 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         for (int q = 0; q < GS_ROWS; ++q) {
             const uint64_t m = __ballot(hit[q]);
             const int pos = cnt[q] + __popcll(m & lt);
-            if (hit[q]) wl[q * (BATCH + 1) + pos] = 48u * (uint32_t)j;
-            if (posmap && j < BATCH) posmap[q * BATCH + j] = hit[q] ? (uint16_t)pos : (uint16_t)0xFFFF;
+            if (hit[q]) wl[q * (BATCH + 1) + pos] = (wl_t)(48u * (uint32_t)j);
+            if (posmap && j < BATCH) posmap[q * BATCH + j] = hit[q] ? (pos_t)pos : POS_NONE;
             cnt[q] += __popcll(m);
         }
     }
     }
     const int nmax = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+    if (cnt_out) {
+#pragma unroll
+        for (int q = 0; q < GS_ROWS; ++q) cnt_out[q] = cnt[q];
+    }
 #pragma unroll
     for (int q = 0; q < GS_ROWS; ++q)
-        for (int p = cnt[q] + lane; p < nmax; p += 64) wl[q * (BATCH + 1) + p] = 48u * (uint32_t)BATCH;
+        for (int p = cnt[q] + lane; p < nmax; p += 64) wl[q * (BATCH + 1) + p] = (wl_t)(48u * (uint32_t)BATCH);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return __builtin_amdgcn_readfirstlane(nmax);      // wave-uniform: keep the visit loop's bound in an SGPR
@@ -273,12 +288,12 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
         for (size_t j = threadIdx.x; j < chunk && z0 + j < zero_n; j += GS_BLOCK) zero_buf[z0 + j] = z;
     }
     __shared__ f4 sq[3 * (BATCH + 1)];
-    __shared__ uint32_t wl_all[NW][GS_ROWS * (BATCH + 1)];
+    __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int lane = threadIdx.x & 63;
-    uint32_t* wl = wl_all[threadIdx.x >> 6];
-    const uint32_t* mylist = wl + (lane >> 4) * (BATCH + 1);
+    wl_t* wl = wl_all[threadIdx.x >> 6];
+    const wl_t* mylist = wl + (lane >> 4) * (BATCH + 1);
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
     float A = 0.f, T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Z = 0.f;
@@ -488,7 +503,16 @@ __device__ __forceinline__ void row_moments_and_totals(float pv, float c0, float
 }
 
 // HAS_ZA: an upstream gradient of the depth or alpha output exists (otherwise u has three terms and the depth sum is skipped)
-template <int BATCH, bool HAS_ZA>
+// POOL > 0: the (block, list position) slots of a batch come out of one pool of POOL slots, handed out per row after the
+// cull (row bases = exclusive scan of the 16 rows' needs: the longest list of the row's wave), instead of BATCH slots per block: the per-block arrays are
+// three quarters empty on the benchmark scene, and they are what sets the kernel's LDS and with it the batch size.  A batch
+// whose lists need more than the pool is culled again with half the pairs (49 of 70 k tile-batches on the benchmark scene
+// at 480 slots; 8.6 % of them at 416, which is why the lists are 16-bit and the position maps 8-bit).  With the pool,
+// 64-pair batches fit the LDS that 32-pair batches with per-block arrays took (26.3 KB, 6 workgroups per CU): half as many
+// batches to stage, cull and synchronise, and four lists twice as long are walked in lockstep with less waste (live rows
+// 0.76 -> 0.79): 0.783 -> 0.713 ms.  Pool sizes 400 / 416 / 448 / 480 / 492: 0.729 / 0.724 / 0.712 / 0.714 / 0.714 ms;
+// 496 slots cross the LDS step to 5 workgroups per CU: 0.748 ms.
+template <int BATCH, bool HAS_ZA, int POOL = 0>
 __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
@@ -500,19 +524,23 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     constexpr int SLOT = 10;                    // floats per (block, list position) slot
     __shared__ f4 sq[3 * (BATCH + 1)];
     __shared__ uint32_t sid[BATCH];
-    __shared__ uint32_t wl_all[NW][GS_ROWS * (BATCH + 1)];
-    __shared__ uint16_t posmap_all[NW][GS_ROWS * BATCH];
+    __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
+    __shared__ pos_t posmap_all[NW][GS_ROWS * BATCH];
 #ifndef GS_SLOT_PAD
 #define GS_SLOT_PAD 4      // measured: 0.8135 ms -> 0.7975 ms (rows of a wave start in different banks)
 #endif
-    constexpr int BSTR = BATCH * SLOT + GS_SLOT_PAD;   // floats between the slot arrays of two blocks
-    __shared__ float slots[NBLK * BSTR + SLOT];        // plain stores, one 40-byte slot per row visit (+ a zero slot)
+    constexpr int BSTR = BATCH * SLOT + GS_SLOT_PAD;   // floats between the slot arrays of two blocks (POOL == 0)
+    constexpr int NSLOTF = POOL > 0 ? POOL * SLOT : NBLK * BSTR;
+    static_assert(POOL == 0 || POOL >= NBLK, "one pair can touch all 16 blocks");
+    __shared__ float slots[NSLOTF + SLOT];             // plain stores, one 40-byte slot per row visit (+ a zero slot)
+    __shared__ uint32_t row_cnt[NBLK];                 // POOL: list length of every 4x4 block, this batch
+    __shared__ uint32_t row_base[POOL > 0 ? NW : 1][NBLK];   // POOL: first slot of every block (a private copy per wave)
     __shared__ uint64_t visited_all[NW];             // bit kk: the wave executed (did not skip) visit kk
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t* wl = wl_all[wave];
-    const uint32_t* mylist = wl + (lane >> 4) * (BATCH + 1);
+    wl_t* wl = wl_all[wave];
+    const wl_t* mylist = wl + (lane >> 4) * (BATCH + 1);
     const uint2 range = ranges[tile];
     const float fpx = (float)c.px, fpy = (float)c.py;
     float gr = 0.f, gg = 0.f, gb = 0.f, gz = 0.f, ga = 0.f, total = 0.f;
@@ -546,12 +574,46 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     // this lane's float inside slot 0 of its row's block
     float* my_slot = slots + (size_t)(wave * GS_ROWS + (lane >> 4)) * BSTR + (vis_slot < 0 ? 0 : vis_slot);
     write_pad_record(sq, BATCH);
-    if (tid < SLOT) slots[NBLK * BSTR + tid] = 0.0f;
-    for (uint32_t base = range.x; base < range.y; base += BATCH) {
+    if (tid < SLOT) slots[NSLOTF + tid] = 0.0f;
+    uint32_t flush_base = 0;                            // POOL: first slot of the block this lane flushes (tid & 15)
+    int n = 0;
+    for (uint32_t base = range.x; base < range.y; base += n) {
         if (__syncthreads_and(P == P_STOPPED)) break;
-        const int n = min((int)(range.y - base), BATCH);
-        const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
-                                               dead_row_mask(P));
+        n = min((int)(range.y - base), BATCH);
+        int nmax;
+        if (POOL > 0) {
+            const uint32_t dead = dead_row_mask(P);
+            for (bool first = true;; first = false) {
+                nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave], dead,
+                                             nullptr, first);
+                // every row of a wave gets the wave's longest list: a wave walks nmax positions with all four rows, and a
+                // row whose own list is shorter still stores (zeros) at the positions behind it
+                if (lane < GS_ROWS) row_cnt[wave * GS_ROWS + lane] = (uint32_t)nmax;
+                __syncthreads();
+                // inclusive scan of the 16 list lengths, in every 16-lane row alike (DPP row shifts: no LDS round trips)
+                const uint32_t own = row_cnt[lane & 15];
+                uint32_t incl = own;
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+                if (total <= (uint32_t)POOL || n == 1) {
+                    flush_base = incl - own;                                                // block tid & 15 = lane & 15
+                    if (lane < NBLK) row_base[wave][lane] = flush_base;                     // own row's base: via LDS, this wave only
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    my_slot = slots + (size_t)row_base[wave][wave * GS_ROWS + (lane >> 4)] * SLOT + (vis_slot < 0 ? 0 : vis_slot);
+                    break;
+                }
+                GS_STAT(10, 1);
+                n = n > 1 ? n / 2 : 1;
+                __syncthreads();        // everybody has read row_cnt and the lists before they are rebuilt
+            }
+        } else {
+            nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
+                                         dead_row_mask(P));
+        }
         uint64_t visited = 0;
         uint32_t off_next = mylist[0];
         GS_STAT(0, 1); GS_STAT(1, nmax); GS_STAT(8, n);
@@ -605,8 +667,8 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         // colour / depth totals.  The conic and opacity factors are applied by gs_preprocess_bwd.
         const int blk = tid & 15;
         const uint64_t blk_visited = visited_all[blk >> 2];
-        const uint16_t* blk_posmap = posmap_all[blk >> 2] + (blk & 3) * BATCH;
-        const float* blk_slots = slots + (size_t)blk * BSTR;
+        const pos_t* blk_posmap = posmap_all[blk >> 2] + (blk & 3) * BATCH;
+        const float* blk_slots = POOL > 0 ? slots + (size_t)flush_base * SLOT : slots + (size_t)blk * BSTR;
         // origin of 4x4 block blk = 4 wave + row (make_ctx)
         const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
         const float blk_x = (float)(tile_x0 + ((blk >> 2) & 1) * GS_SUB + (blk & 1) * GS_QUAD);
@@ -615,14 +677,14 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         for (int r = 0; r < BATCH / 16; ++r) {
             const int j = r * 16 + (tid >> 4);
             const uint32_t pos = blk_posmap[j];
-            const bool valid = j < n && pos != 0xFFFFu && ((blk_visited >> pos) & 1ull);
+            const bool valid = j < n && pos != (uint32_t)POS_NONE && ((blk_visited >> pos) & 1ull);
             const uint64_t vm = __ballot(valid);
             GS_STAT(6, 1); GS_STAT(9, __popcll(vm));
             if (vm == 0) continue;                   // wave-uniform: none of this wave's 4 pairs was visited
             GS_STAT(7, 1);
             const bool any = ((vm >> (lane & 48)) & 0xFFFFull) != 0;
             // lanes without a slot read the always-zero slot behind the last one
-            const float* sl = valid ? blk_slots + pos * SLOT : slots + NBLK * BSTR;
+            const float* sl = valid ? blk_slots + pos * SLOT : slots + NSLOTF;
             float m[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) m[k] = sl[k];
@@ -704,11 +766,11 @@ extern "C" int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ra
     const int tile0 = tile_row_begin * tiles_x, ntiles = tiles_x * (tile_row_end - tile_row_begin);
     GS_REQUIRE(((uintptr_t)grad_rows & 15) == 0, "grad_rows must be 16-byte aligned");
     if (g_depth || g_alpha)
-        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, true>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, true, GS_BWD_POOL>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
                            (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
                            g_image, g_depth, g_alpha, grad_rows, t_eps);
     else
-        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, false>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
+        hipLaunchKernelGGL((render_bwd_kernel<GS_BWD_BATCH, false, GS_BWD_POOL>), dim3(ntiles), dim3(GS_BLOCK), 0, (hipStream_t)stream_, H, W, tiles_x, tile0, ntiles,
                            (const float4*)splat, (const uint2*)ranges, point_list, aux_rgb, out_depth, out_alpha,
                            g_image, g_depth, g_alpha, grad_rows, t_eps);
     GS_CHECK_LAUNCH("render_bwd");

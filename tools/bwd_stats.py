@@ -17,4 +17,5 @@ for t_eps in (1e-5, 0.0):
     out = (C.c_ulonglong * 16)(); lib.gs_dbg_read(out); v = list(out)
     print(f"t_eps {t_eps}: wave-batches {v[0]}, pairs staged (x4 waves) {v[8]}, sum nmax {v[1]}, loop iterations {v[2]}, executed visits {v[3]}, "
           f"active lanes {v[4]} ({v[4]/max(v[3],1)/64:.3f} of the lanes of executed visits), live rows {v[5]} ({v[5]/max(v[3],1)/4:.3f}), "
-          f"flush rounds {v[6]} (executed {v[7]}), valid flush lanes {v[9]} ({v[9]/max(v[7],1)/64:.3f})")
+          f"flush rounds {v[6]} (executed {v[7]}), valid flush lanes {v[9]} ({v[9]/max(v[7],1)/64:.3f}), "
+          f"batches culled again for the slot pool (x4 waves) {v[10]}")

@@ -67,7 +67,8 @@ constexpr float GS_LOG2E = 1.4426950408889634f;
 constexpr int GS_ROWS = 4;                 // 16-lane rows per wave, one 4x4 pixel block each
 constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #ifndef GS_FWD_BATCH_DEF
-#define GS_FWD_BATCH_DEF 128     // pairs per forward batch (64 and 256 measured: see DESIGN.md)
+#define GS_FWD_BATCH_DEF 192     // pairs per forward batch: 128 / 192 / 256 = 0.290 / 0.279 / 0.277 ms at config 3 with 16-bit lists
+                                 // (15.5 KB of LDS at 192; config 5: 3.17 / 3.10 / 3.11 ms, config 2: 0.49 / 0.45 / 0.47 ms)
 #endif
 #ifndef GS_BWD_BATCH_DEF
 #define GS_BWD_BATCH_DEF 64

@@ -142,14 +142,19 @@ def _scene_settings(dgr, sc, dev):
 
 
 @pytest.mark.parametrize("N,K,H,W,seed,clustered", [(20000, 16, 300, 420, 3, False), (60000, 4, 203, 317, 4, False),
-                                                    (40000, 16, 240, 320, 5, True)])
+                                                    (40000, 16, 240, 320, 5, True), (3000, 4, 100, 116, 6, "big")])
 def test_midsize_vs_oracle(dgr, oracle, N, K, H, W, seed, clustered):
     """Sizes the reference cannot reach in reasonable time; the pinned oracle is the checker.
     clustered: 70 % of the Gaussians pulled into two small regions -- a few tiles carry lists ~30x the mean, most
-    pixels there saturate early, other tiles are nearly empty (what a real capture looks like next to the 8d scene)."""
+    pixels there saturate early, other tiles are nearly empty (what a real capture looks like next to the 8d scene).
+    "big": faint splats twelve times the usual size -- every pair of a tile touches all 16 of its 4x4 blocks and nothing
+    saturates, so every backward batch needs more slots than the pool holds and is culled again with fewer pairs."""
     syn = importlib.import_module("gaussian-splatting_amd.synthetic")
     sc = syn.make_scene(N, K, H, W, seed=seed)
-    if clustered:
+    if clustered == "big":
+        sc.scales = (sc.scales * 12.0).contiguous()
+        sc.opacities = (sc.opacities * 0.03).contiguous()
+    elif clustered:
         g0 = torch.Generator().manual_seed(seed)
         m = torch.rand(N, generator=g0) < 0.7
         centres = torch.tensor([[0.6, -0.3, 4.0], [-1.0, 0.5, 6.0]])

@@ -1,4 +1,5 @@
 """Utilisation counters of render_bwd on the bench scene (config 3), default t_eps and t_eps = 0.
+usage: bwd_stats.py [big]   (big = a small scene of huge faint splats: every batch overflows the slot pool)
 Needs the stats build:  tools/build_variant.sh stats -DGS_STATS  &&  GSPLAT_LIB=$PWD/gaussian-splatting_amd/lib/var_stats.so python tools/bwd_stats.py"""
 import ctypes as C, importlib, os, sys, torch
 sys.path.insert(0, os.getcwd())
@@ -7,7 +8,11 @@ syn = importlib.import_module("gaussian-splatting_amd.synthetic")
 L = importlib.import_module("gaussian-splatting_amd._lib")
 lib = C.CDLL(L.LIB_PATH)
 dev = torch.device("cuda:0")
-sc = syn.make_scene(3_000_000, 16, 840, 1297, seed=0)
+if len(sys.argv) > 1 and sys.argv[1] == "big":     # the pool-overflow scene of tests/test_gpu_parity.py::test_midsize_vs_oracle
+    sc = syn.make_scene(3000, 4, 100, 116, seed=6)
+    sc.scales, sc.opacities = sc.scales * 12.0, sc.opacities * 0.03
+else:
+    sc = syn.make_scene(3_000_000, 16, 840, 1297, seed=0)
 p = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
 for t_eps in (1e-5, 0.0):
     st = dgr.GaussianRasterizationSettings(image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=sc.bg.to(dev), scale_modifier=1.0, viewmatrix=sc.viewmatrix.to(dev), projmatrix=sc.projmatrix.to(dev), sh_degree=sc.sh_degree, campos=sc.campos.to(dev), prefiltered=False, debug=False)

@@ -36,6 +36,7 @@ def test_housekeeping_calls_work_without_a_gpu():
     assert lib.gs_version() >= 100
     assert lib.gs_tile_size() == 16
     assert lib.gs_grad_row_floats() == 16
+    assert lib.gs_sh_jac_row_floats() == 12
     assert lib.gs_scan_workspace_bytes(3_000_000) >= 4 * (3_000_000 // 4096)
     assert lib.gs_sort_workspace_bytes(7_535_647) >= 256 * 4 * (7_535_647 // 4096)
     # argument errors are reported through the return code + gs_last_error, never a crash

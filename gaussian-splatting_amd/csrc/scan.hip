@@ -1,8 +1,8 @@
 // Pair offsets: device-wide exclusive prefix sum of the per-Gaussian tile counts, in depth order.
 // No counterpart in the reference (its rasterizer has no binning stage).
 //
-// Three launches: per-block sums (which also gathers every Gaussian's box into depth order), one
-// workgroup scanning the block sums, per-block scan + base.
+// Two launches: per-block sums (which also gathers every Gaussian's box into depth order), then per-block scan + base,
+// every workgroup adding up the block sums before it (beyond 16.8 M Gaussians: a one-workgroup scan of the sums between).
 // HBM-bound: per Gaussian 8 B read + one gathered record line, 8 B written, 8 B read, 4 B written.
 #include "gsplat_common.h"
 
@@ -11,6 +11,7 @@ namespace {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;  // consecutive elements per lane
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int SCAN_FUSE_MAX = 4096;   // workgroups (16.8 M Gaussians) up to which the final pass sums the block totals itself
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -82,12 +83,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_rect_kernel(
 
 // Striped arrangement so that every load and store is coalesced: wave w of the workgroup owns 1024
 // consecutive elements and walks them in 16 rounds of 64.
+// SUMS_RAW: block_sums holds the totals as scan_reduce_rect left them -- every workgroup adds up the totals before
+// it by itself (a few coalesced reads out of L2 per lane at up to SCAN_FUSE_MAX workgroups) and the last one writes the grand
+// total: no single-workgroup launch between the two passes.
+template <bool SUMS_RAW>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_rect_kernel(const uint2* __restrict__ rect, long long n,
                                                                         int row_b, int row_e,
                                                                         const uint32_t* __restrict__ block_sums,
-                                                                        uint32_t* __restrict__ out) {
+                                                                        uint32_t* __restrict__ out,
+                                                                        uint32_t* __restrict__ total_out) {
     __shared__ uint32_t wave_total[SCAN_THREADS / 64];
+    __shared__ uint32_t wave_before[SCAN_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t before = 0;
+    if (SUMS_RAW) {
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) before += block_sums[b];
+    }
     const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)wave * (64 * SCAN_ITEMS) + lane;
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
@@ -104,8 +115,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_rect_kernel(const uin
     }
     const uint32_t wsum = wave_incl_scan(s, lane);   // lane 63: this wave's total
     if (lane == 63) wave_total[wave] = wsum;
+    if (SUMS_RAW) {
+        before = wave_incl_scan(before, lane);
+        if (lane == 63) wave_before[wave] = before;
+    }
     __syncthreads();
-    uint32_t run = block_sums[blockIdx.x];
+    uint32_t run;
+    if (SUMS_RAW) {
+        run = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) run += wave_before[w];
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && total_out) {
+            uint32_t tot = run;
+#pragma unroll
+            for (int w = 0; w < SCAN_THREADS / 64; ++w) tot += wave_total[w];
+            *total_out = tot;
+        }
+    } else {
+        run = block_sums[blockIdx.x];
+    }
     for (int w = 0; w < wave; ++w) run += wave_total[w];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
@@ -144,10 +172,15 @@ extern "C" int gs_scan_tiles(long long N, const void* rects, const uint32_t* ord
         hipLaunchKernelGGL(scan_reduce_rect_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint2*)rects,
                            order, (uint2*)rect_in_order, N, tile_row_begin, tile_row_end, sums);
         GS_CHECK_LAUNCH("scan_reduce_rect");
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks, total_dev);
-        GS_CHECK_LAUNCH("scan_sums");
-        hipLaunchKernelGGL(scan_final_rect_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream,
-                           (const uint2*)rect_in_order, N, tile_row_begin, tile_row_end, sums, offsets);
+        if (nblocks <= SCAN_FUSE_MAX) {
+            hipLaunchKernelGGL((scan_final_rect_kernel<true>), dim3(nblocks), dim3(SCAN_THREADS), 0, stream,
+                               (const uint2*)rect_in_order, N, tile_row_begin, tile_row_end, sums, offsets, total_dev);
+        } else {
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks, total_dev);
+            GS_CHECK_LAUNCH("scan_sums");
+            hipLaunchKernelGGL((scan_final_rect_kernel<false>), dim3(nblocks), dim3(SCAN_THREADS), 0, stream,
+                               (const uint2*)rect_in_order, N, tile_row_begin, tile_row_end, sums, offsets, total_dev);
+        }
         GS_CHECK_LAUNCH("scan_final_rect");
     }
     if (host_total) {

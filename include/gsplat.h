@@ -123,7 +123,9 @@ long long gs_sort_pairs_static_max(void);
 int gs_sort_pairs_static(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
                          uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int* result_in_b, void* stream);
 /* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty); count_dev as
- * in gs_sort_pairs. */
+ * in gs_sort_pairs.  keys = tile ids < num_tiles in ascending order (16-byte aligned; a key >= num_tiles
+ * writes nothing).  Every entry of `ranges` (8-byte aligned) is written by the call -- the entries of empty
+ * tiles too, by whoever sees the keys on either side of them -- so the table needs no clearing. */
 int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, int num_tiles, const uint32_t* keys,
                             uint32_t* ranges, void* stream);
 

@@ -342,6 +342,79 @@ def test_sort_pairs_stable_on_bit_range(n, bits, use_count):
     assert np.array_equal(vo.cpu().numpy().view(np.uint32)[:n], vals[:n][perm])
 
 
+@pytest.mark.parametrize("n,num_tiles,distinct,use_count", [
+    (0, 37, 0, False), (0, 70000, 0, True), (1, 5, 1, False), (7, 9, 3, False), (8, 4346, 2, True),
+    (2049, 4346, 4346, False), (100003, 4346, 3000, True), (300001, 65536, 40, True), (50000, 65536, 65536, False)])
+def test_identify_tile_ranges_sparse_and_ragged(n, num_tiles, distinct, use_count):
+    """gs_identify_tile_ranges through the C-ABI on synthetic sorted tile ids: empty lists, list lengths that are no
+    multiple of the lane's 8 keys, a handful of tiles out of 65536 (long runs of empty tiles, before the first and behind
+    the last key too), every tile used, count from device memory with a larger capacity.  The table is NOT cleared by
+    the caller: every entry must come out of the kernel.  Bit-exact against a numpy restatement (searchsorted)."""
+    import ctypes as C
+    lib = importlib.import_module("gaussian-splatting_amd._lib")
+    L = lib.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + num_tiles)
+    if n:
+        tiles = np.sort(rng.choice(num_tiles, size=min(distinct, num_tiles), replace=False))
+        keys = np.sort(rng.choice(tiles, size=n)).astype(np.uint32)
+    else:
+        keys = np.zeros(0, np.uint32)
+    cap = n + 777 if use_count else n
+    buf = np.full(max(cap, 8), 0xDEADBEEF, np.uint32)          # garbage behind the count must not be read as keys
+    buf[:n] = keys
+    kd = torch.from_numpy(buf.view(np.int32).copy()).to(dev)
+    ranges = torch.full((num_tiles, 2), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev) if use_count else None
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())  # noqa: E731
+    rc = L.gs_identify_tile_ranges(cap, p(cnt), num_tiles, p(kd), p(ranges),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gs_last_error()
+    torch.cuda.synchronize()
+    ids = np.arange(num_tiles)
+    lo, hi = np.searchsorted(keys, ids, side="left"), np.searchsorted(keys, ids, side="right")
+    want = np.stack([np.where(hi > lo, lo, 0), np.where(hi > lo, hi, 0)], axis=1).astype(np.uint32)
+    got = ranges.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,band", [(1, None), (4095, None), (4097, (1, 3)), (300_001, None), (17_000_000, (2, 40))])
+def test_scan_tiles_offsets_and_total(n, band):
+    """gs_scan_tiles through the C-ABI: boxes gathered into the given order, exclusive scan of their tile counts (inside a
+    band of tile rows when one is given) and the total, bit-exact against numpy's cumsum.  17 M boxes take the path with
+    the one-workgroup scan of the block sums between the two passes (more than 4096 workgroups)."""
+    import ctypes as C
+    lib = importlib.import_module("gaussian-splatting_amd._lib")
+    L = lib.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    x0, y0 = rng.integers(0, 1200, n), rng.integers(0, 800, n)
+    w, h = rng.integers(0, 60, n), rng.integers(0, 60, n)            # width or height 0: an empty box
+    rects = np.stack([x0 | (x0 + w) << 16, y0 | (y0 + h) << 16], axis=1).astype(np.uint32)
+    order = rng.permutation(n).astype(np.uint32)
+    rb, re = band if band else (0, 1 << 20)
+    r = rects[order]
+    xmin, xmax, ymin, ymax = r[:, 0] & 0xFFFF, r[:, 0] >> 16, r[:, 1] & 0xFFFF, r[:, 1] >> 16
+    ok = (xmax > xmin) & (ymax > ymin)
+    tx0, tx1 = xmin // 16, (xmax.astype(np.int64) - 1) // 16 + 1
+    ty0, ty1 = np.maximum(ymin // 16, rb), np.minimum((ymax.astype(np.int64) - 1) // 16 + 1, re)
+    cnt = np.where(ok & (ty1 > ty0), (tx1 - tx0) * (ty1 - ty0), 0).astype(np.int64)
+    want = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.uint32)
+    t = lambda a: torch.from_numpy(a.view(np.int32).copy()).to(dev)  # noqa: E731
+    d_rects, d_order = t(rects), t(order)
+    d_rio, d_off = torch.empty_like(d_rects), torch.empty((n,), dtype=torch.int32, device=dev)
+    total = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(16, L.gs_scan_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    rc = L.gs_scan_tiles(n, p(d_rects), p(d_order), p(d_rio), p(d_off), p(total), p(ws), None, rb, re,
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gs_last_error()
+    torch.cuda.synchronize()
+    assert int(total.item()) == int(cnt.sum())
+    assert np.array_equal(d_rio.cpu().numpy().view(np.uint32), r)
+    assert np.array_equal(d_off.cpu().numpy().view(np.uint32), want)
+
+
 def test_backward_twice_and_unused_outputs(dgr):
     """retain_graph: the second backward clears its own gradient rows (the first used the rows the
     forward kernel cleared); a loss on depth alone leaves the image gradient undefined (None)."""

@@ -247,7 +247,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     }
 #pragma unroll
     for (int q = 0; q < GS_ROWS; ++q)
-        for (int p = cnt[q] + lane; p < nmax; p += 64) wl[q * (BATCH + 1) + p] = (wl_t)(48u * (uint32_t)BATCH);
+        for (int p = cnt[q] + lane; p < ((nmax + 1) & ~1); p += 64) wl[q * (BATCH + 1) + p] = (wl_t)(48u * (uint32_t)BATCH);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return __builtin_amdgcn_readfirstlane(nmax);      // wave-uniform: keep the visit loop's bound in an SGPR
@@ -435,7 +435,7 @@ __device__ __forceinline__ void add_to_row(float* row, int idx, float v) {
 // Colours: two select-free halvings over the banks, then the quad sum -- every lane of bank j ends with the row
 // total of c_j (8 DPP adds, 7 without c3).  16 half-rate instructions per visit instead of 22, and the five
 // products q dx, q dy, q dx^2, q dx dy, q dy^2 are never formed.  k[] = this lane's seven map coefficients.
-struct MomentCoef { float a, b, c, d0, d1, d2, d3; };
+struct MomentCoef { float a, b, c, d0, d2; };
 __device__ __forceinline__ MomentCoef moment_coef(int lane) {
     const int x = lane & 3, y = (lane >> 2) & 3;
     MomentCoef k;
@@ -443,9 +443,7 @@ __device__ __forceinline__ MomentCoef moment_coef(int lane) {
     k.b = x == 0 ? 1.0f : (x == 1 ? 2.0f : (x == 2 ? 4.0f : 0.0f));   // t[2]
     k.c = x == 1 ? 0.5f : (x == 2 ? 2.5f : 0.0f);             // t[3]
     k.d0 = y == 2 ? 4.0f : (y == 3 ? 0.0f : 1.0f);            // own bank
-    k.d1 = 1.0f;                                              // bank + 2 (written in banks 0, 1 only)
-    k.d2 = y == 1 ? 2.0f : 5.0f;                              // bank + 1 (written in banks 1, 2 only)
-    k.d3 = 1.0f;                                              // bank - 1 (written in bank 2 only)
+    k.d2 = y == 1 ? 2.0f : 5.0f;                              // bank + 1 (written in banks 1, 2 only); banks + 2 and - 1 enter with 1: plain DPP adds
     return k;
 }
 
@@ -469,14 +467,13 @@ __device__ __forceinline__ void row_moments_and_totals(float pv, float c0, float
             "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_mul_f32 %4, %14, %1\n\t"
             "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %4, %1, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_fmac_f32_dpp %4, %1, %16 row_shl:4 row_mask:0xf bank_mask:0x6\n\t"
+            "v_add_f32_dpp %4, %1, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_fmac_f32_dpp %4, %1, %15 row_shl:4 row_mask:0xf bank_mask:0x6\n\t"
             "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %4, %1, %17 row_shr:4 row_mask:0xf bank_mask:0x4\n\t"
+            "v_add_f32_dpp %4, %1, %4 row_shr:4 row_mask:0xf bank_mask:0x4\n\t"
             "s_nop 1"
             : "=&v"(t), "=&v"(u), "=&v"(e0), "=&v"(e1), "=&v"(r), "=&v"(f)
-            : "v"(pv), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(k.a), "v"(k.b), "v"(k.c), "v"(k.d0), "v"(k.d1),
-              "v"(k.d2), "v"(k.d3));
+            : "v"(pv), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(k.a), "v"(k.b), "v"(k.c), "v"(k.d0), "v"(k.d2));
     } else {
         asm volatile(
             "s_nop 1\n\t"
@@ -492,14 +489,13 @@ __device__ __forceinline__ void row_moments_and_totals(float pv, float c0, float
             "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_mul_f32 %4, %14, %1\n\t"
             "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0x7\n\t"
-            "v_fmac_f32_dpp %4, %1, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_fmac_f32_dpp %4, %1, %16 row_shl:4 row_mask:0xf bank_mask:0x6\n\t"
+            "v_add_f32_dpp %4, %1, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_fmac_f32_dpp %4, %1, %15 row_shl:4 row_mask:0xf bank_mask:0x6\n\t"
             "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0x7\n\t"
-            "v_fmac_f32_dpp %4, %1, %17 row_shr:4 row_mask:0xf bank_mask:0x4\n\t"
+            "v_add_f32_dpp %4, %1, %4 row_shr:4 row_mask:0xf bank_mask:0x4\n\t"
             "s_nop 1"
             : "=&v"(t), "=&v"(u), "=&v"(e0), "=&v"(e1), "=&v"(r), "=&v"(f)
-            : "v"(pv), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(k.a), "v"(k.b), "v"(k.c), "v"(k.d0), "v"(k.d1),
-              "v"(k.d2), "v"(k.d3));
+            : "v"(pv), "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(k.a), "v"(k.b), "v"(k.c), "v"(k.d0), "v"(k.d2));
     }
 }
 
@@ -618,13 +614,14 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         uint64_t visited = 0;
         uint32_t off_next = mylist[0];
         GS_STAT(0, 1); GS_STAT(1, nmax); GS_STAT(8, n);
-        for (int kk = 0; kk < nmax; ++kk) {
-            if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
+        // two visits per trip (list pointer and slot pointer advance once, the second visit uses immediate offsets); an odd
+        // nmax ends on the padding record behind the lists (stage_and_cull pads to an even length), which is skipped
+        auto visit = [&](const int kk) {
             GS_STAT(2, 1);
             const Rec rec = load_rec(sq, off_next);
             off_next = mylist[kk + 1];
             const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
-            if (!__any(act)) continue;
+            if (!__any(act)) return;
 #ifdef GS_STATS
             {
                 const uint64_t am = __ballot(act);
@@ -659,6 +656,11 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             float mom, tot;
             row_moments_and_totals<HAS_ZA>(pv, c_rg.x, c_rg.y, c_b, c_z, mk, mom, tot);
             if (vis_slot >= 0) my_slot[kk * SLOT] = t == 3 ? tot : mom;   // one ds_write_b32 per visit, 10 lanes per row
+        };
+        for (int kk = 0; kk < nmax; kk += 2) {
+            if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
+            visit(kk);
+            visit(kk + 1);
         }
         if (lane == 0) visited_all[wave] = visited;
         __syncthreads();

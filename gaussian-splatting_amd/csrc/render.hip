@@ -253,6 +253,24 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     return __builtin_amdgcn_readfirstlane(nmax);      // wave-uniform: keep the visit loop's bound in an SGPR
 }
 
+// List entries (u16 record offsets) are read with hand-issued ds_read_u16: through the compiler the loop-carried entry
+// stays a 16-bit value and every visit pays a v_and_b32 0xffff before it can address the record, although the read has
+// zero-extended it already, and the second visit of an unrolled trip pays an address add that the instruction's
+// immediate offset covers.  The result of an asm is opaque to the compiler's wait-count bookkeeping, so the wait is
+// written by hand too (list_wait, right before the first use); extra LDS reads in flight only make the compiler's own
+// waits conservative (LDS returns in order).
+template <int BYTE_OFF>
+__device__ __forceinline__ uint32_t list_read(uint32_t lds_addr) {
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(BYTE_OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void list_wait(uint32_t& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+template <int V> struct IntC { static constexpr int value = V; };
+
 // bit q: all 16 lanes of DPP row q of this wave have stopped (wave-uniform)
 __device__ __forceinline__ uint32_t dead_row_mask(uint32_t P) {
     const uint64_t st = __ballot(P == P_STOPPED);
@@ -305,11 +323,14 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
         const int n = min((int)(range.y - base), BATCH);
         const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr,
                                                dead_row_mask(P));
-        uint32_t off_next = mylist[0];   // list entry one visit ahead: one LDS latency per visit, not two
-        for (int kk = 0; kk < nmax; ++kk) {
-            if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
+        // list entry one visit ahead (one LDS latency per visit, not two); two visits per trip: an odd nmax ends on the
+        // padding record behind the lists (stage_and_cull pads to an even length), whose alpha is 0
+        uint32_t lp = lds_addr_of(mylist);
+        uint32_t off_next = list_read<0>(lp);
+        auto visit = [&](auto next_off) {
+            list_wait(off_next);
             const Rec rec = load_rec(sq, off_next);
-            off_next = mylist[kk + 1];       // entry nmax is never used (lists have BATCH + 1 entries)
+            off_next = list_read<decltype(next_off)::value>(lp);       // entry nmax + 1 is never used
             const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
             const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
             const float power2 = gauss_power2(rec, dx, dy);
@@ -322,6 +343,11 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
             A += alpha;
             T = 1.0f - A;
             P = T <= t_eps ? P_STOPPED : P;   // t_eps = 0: stops at T == 0 exactly, where every later alpha is 0 anyway
+        };
+        for (int kk = 0; kk < nmax; kk += 2, lp += 2 * sizeof(wl_t)) {
+            if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
+            visit(IntC<sizeof(wl_t)>());
+            visit(IntC<2 * sizeof(wl_t)>());
         }
     }
     if (c.inside) {
@@ -612,14 +638,16 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                                          dead_row_mask(P));
         }
         uint64_t visited = 0;
-        uint32_t off_next = mylist[0];
+        uint32_t lp = lds_addr_of(mylist);
+        uint32_t off_next = list_read<0>(lp);
         GS_STAT(0, 1); GS_STAT(1, nmax); GS_STAT(8, n);
         // two visits per trip (list pointer and slot pointer advance once, the second visit uses immediate offsets); an odd
         // nmax ends on the padding record behind the lists (stage_and_cull pads to an even length), which is skipped
-        auto visit = [&](const int kk) {
+        auto visit = [&](const int kk, auto next_off) {
             GS_STAT(2, 1);
+            list_wait(off_next);
             const Rec rec = load_rec(sq, off_next);
-            off_next = mylist[kk + 1];
+            off_next = list_read<decltype(next_off)::value>(lp);
             const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
             if (!__any(act)) return;
 #ifdef GS_STATS
@@ -657,10 +685,10 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             row_moments_and_totals<HAS_ZA>(pv, c_rg.x, c_rg.y, c_b, c_z, mk, mom, tot);
             if (vis_slot >= 0) my_slot[kk * SLOT] = t == 3 ? tot : mom;   // one ds_write_b32 per visit, 10 lanes per row
         };
-        for (int kk = 0; kk < nmax; kk += 2) {
+        for (int kk = 0; kk < nmax; kk += 2, lp += 2 * sizeof(wl_t)) {
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
-            visit(kk);
-            visit(kk + 1);
+            visit(kk, IntC<sizeof(wl_t)>());
+            visit(kk + 1, IntC<2 * sizeof(wl_t)>());
         }
         if (lane == 0) visited_all[wave] = visited;
         __syncthreads();

@@ -31,11 +31,12 @@ constexpr int RS_RADIX = 256;
 constexpr int RS_GROUP = 32;                    // workgroups per grp row
 constexpr int RS_MAX_PASSES = 4;
 
-// lanes of this wave holding the same 8-bit digit (only among `valid` lanes)
+// lanes of this wave holding the same NBITS-bit digit (only among `valid` lanes)
+template <int NBITS>
 __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid) {
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NBITS; ++b) {
         const bool bit = (digit >> b) & 1u;
         const uint64_t m = __ballot(bit);
         peers &= bit ? m : ~m;
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
     if (c) atomicAdd(&grp[(size_t)(blockIdx.x / RS_GROUP) * RS_RADIX + threadIdx.x], c);
 }
 
+// NBITS: width of this pass's digit (the last pass of a bit range that is no multiple of 8 is narrower -- the tile sort's
+// second pass has 5 bits at 4 346 tiles -- and ranks its keys with that many ballots instead of 8)
+template <int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, long long cap, const uint32_t* __restrict__ count_dev, int shift, uint32_t mask,
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         const long long idx = base + it * 64 + lane;
         const bool valid = idx < D;
         const uint32_t d = (key[it] >> shift) & mask;
-        const uint64_t peers = match_digit(d, valid);
+        const uint64_t peers = match_digit<NBITS>(d, valid);
         uint32_t prior = 0;
         if (valid) prior = my_cnt[d];  // every peer reads the same counter ...
         __builtin_amdgcn_wave_barrier();
@@ -253,8 +257,18 @@ static int sort_pairs_impl(long long D, const uint32_t* count_dev, int bit_begin
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, D, count_dev, shift, mask,
                            blk, grp);
         GS_CHECK_LAUNCH("radix_hist");
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd, D,
-                           count_dev, shift, mask, blk, grp);
+        const int nbits = bit_end - shift >= 8 ? 8 : bit_end - shift;
+#define GS_SCATTER(NB)                                                                                              \
+    hipLaunchKernelGGL((radix_scatter_kernel<NB>), dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd, D, \
+                       count_dev, shift, mask, blk, grp)
+        switch (nbits) {
+            case 1: case 2: case 3: case 4: GS_SCATTER(4); break;
+            case 5: GS_SCATTER(5); break;
+            case 6: GS_SCATTER(6); break;
+            case 7: GS_SCATTER(7); break;
+            default: GS_SCATTER(8); break;
+        }
+#undef GS_SCATTER
         GS_CHECK_LAUNCH("radix_scatter");
         uint32_t* tk = ks; ks = kd; kd = tk;
         uint32_t* tv = vs; vs = vd; vd = tv;

@@ -167,7 +167,7 @@ __device__ __forceinline__ TileCtx make_ctx(int tile, int tiles_x, int H, int W)
 // of the longest list.
 template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
-                                              uint32_t base, int n, const TileCtx& c, f4* sq, uint32_t* sid,
+                                              uint32_t base, int n, const TileCtx& c, f4* sq, uint2* sid,
                                               wl_t* wl, pos_t* posmap, uint32_t dead_rows,
                                               int* cnt_out = nullptr, bool load = true) {
     static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
@@ -176,11 +176,17 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         const uint32_t id = point_list[base + tid];
         const f4* p = splat + 3 * (size_t)id;
         f4 p0 = p[0], p1 = p[1], p2 = p[2];
+        if (sid) {
+            // the backward's flush wants the Gaussian's index and the centre of its box (the integer pixel its moments are
+            // taken about): formed once per pair here instead of once per lane and flush round
+            const uint32_t rx = __float_as_uint(p1.w), ry = __float_as_uint(p2.w);
+            const uint32_t cx = ((rx & 0xFFFFu) + ((rx >> 16) - 1u)) >> 1, cy = ((ry & 0xFFFFu) + ((ry >> 16) - 1u)) >> 1;
+            sid[tid] = make_uint2(id, cx | (cy << 16));
+        }
         to_lds_form(p0, p1, p2);
         sq[3 * tid] = p0;
         sq[3 * tid + 1] = p1;
         sq[3 * tid + 2] = p2;
-        if (sid) sid[tid] = id;
     }
     __syncthreads();
     const int lane = tid & 63;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     constexpr int NBLK = NW * GS_ROWS;          // 16 4x4 blocks per tile
     constexpr int SLOT = 10;                    // floats per (block, list position) slot
     __shared__ f4 sq[3 * (BATCH + 1)];
-    __shared__ uint32_t sid[BATCH];
+    __shared__ uint2 sid[BATCH];                       // (Gaussian index, centre of its box as x | y << 16)
     __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
     __shared__ pos_t posmap_all[NW][GS_ROWS * BATCH];
 #ifndef GS_SLOT_PAD
@@ -723,10 +729,9 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             // every tile derives identically): dx_o = (block origin - centre) + lx with small exact integers, so
             // nothing is lost here however far away the mean is; gs_preprocess_bwd moves the sums to the mean, in
             // double, once per Gaussian
-            const f4 r1 = sq[3 * j + 1];
-            const uint32_t blo = __float_as_uint(r1.z), bhi = __float_as_uint(r1.w);
-            const float ex = blk_x - (float)(((blo & 0xFFFFu) + (bhi & 0xFFFFu)) >> 1);
-            const float ey = blk_y - (float)(((blo >> 16) + (bhi >> 16)) >> 1);
+            const uint2 idc = sid[j];
+            const float ex = blk_x - (float)(idc.y & 0xFFFFu);
+            const float ey = blk_y - (float)(idc.y >> 16);
             const float exM = ex * m[0], eyM = ey * m[0];
             float v[10];
             v[0] = exM + m[1];
@@ -742,7 +747,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const float sum = row_reduce_scatter10<HAS_ZA>(v, t);
             if (any && red_slot >= 0) {
                 const float outv = sum;
-                add_to_row(grad_rows + (size_t)sid[j] * GS_GRAD_ROW, red_slot, outv);
+                add_to_row(grad_rows + (size_t)idc.x * GS_GRAD_ROW, red_slot, outv);
             }
         }
     }

@@ -76,7 +76,7 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #ifndef GS_BWD_POOL
 #define GS_BWD_POOL 480     // slots of the backward's pool (0 = BATCH slots per block); measured 400..492: see render_bwd_kernel
 #endif
-constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch (at most 64: one visited bit per list position)
+constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch (list positions are 8-bit; more than 64 pairs is untested)
 
 // LDS form of a splat record (written by stage_and_cull):
 //   q0 = (mean_x, mean_y, A', B')   q1 = (C', opacity, x_min | y_min << 16, (x_max - 1) | (y_max - 1) << 16)
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     __shared__ float slots[NSLOTF + SLOT];             // plain stores, one 40-byte slot per row visit (+ a zero slot)
     __shared__ uint32_t row_cnt[NBLK];                 // POOL: list length of every 4x4 block, this batch
     __shared__ uint32_t row_base[POOL > 0 ? NW : 1][NBLK];   // POOL: first slot of every block (a private copy per wave)
-    __shared__ uint64_t visited_all[NW];             // bit kk: the wave executed (did not skip) visit kk
+    __shared__ uint32_t walked_all[NW];              // list positions the wave walked this batch (all of them unless every pixel stopped)
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     if (t == 0) red_slot = ((bank & 1) ? 2 : 0) + 5 * (bank >> 1);
     else if (t == 1) red_slot = ((bank & 1) ? 3 : 1) + 5 * (bank >> 1);
     else if (t == 2 && !(bank & 1) && (HAS_ZA || bank == 0)) red_slot = 4 + 5 * (bank >> 1);
-    static_assert(BATCH <= 64 && BATCH % 16 == 0, "64-bit visited mask; the flush takes 16 pairs per round");
+    static_assert(BATCH <= 64 && BATCH % 16 == 0, "tested up to 64 pairs; the flush takes 16 pairs per round");
     // what this lane stores per visit (row_moments_and_totals): slot = [M00 M10 M20 M01 M11 M02 | c0 c1 c2 c3]
     int vis_slot = -1;
     if (t == 3) vis_slot = (bank < 3 || HAS_ZA) ? 6 + bank : -1;
@@ -643,7 +643,6 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
                                          dead_row_mask(P));
         }
-        uint64_t visited = 0;
         uint32_t lp = lds_addr_of(mylist);
         uint32_t off_next = list_read<0>(lp);
         GS_STAT(0, 1); GS_STAT(1, nmax); GS_STAT(8, n);
@@ -655,7 +654,12 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const Rec rec = load_rec(sq, off_next);
             off_next = list_read<decltype(next_off)::value>(lp);
             const bool act = in_box(P, __float_as_uint(rec.q1.z), __float_as_uint(rec.q1.w));
-            if (!__any(act)) return;
+            if (!__any(act)) {
+                // no lane of the wave is inside this box: the slot still gets its zeros (the flush takes every walked
+                // position), except behind the lists -- an odd nmax ends on the padding record, which owns no slot
+                if (kk < nmax && vis_slot >= 0) my_slot[kk * SLOT] = 0.0f;
+                return;
+            }
 #ifdef GS_STATS
             {
                 const uint64_t am = __ballot(act);
@@ -663,7 +667,6 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                 GS_STAT(5, ((am & 0xFFFFull) != 0) + (((am >> 16) & 0xFFFFull) != 0) + (((am >> 32) & 0xFFFFull) != 0) + ((am >> 48) != 0));
             }
 #endif
-            visited |= 1ull << kk;
             const float dx = fpx - rec.q0.x, dy = fpy - rec.q0.y;
             const float power2 = gauss_power2(rec, dx, dy);
             const float G = act ? __builtin_amdgcn_exp2f(power2) : 0.0f;  // inactive lanes: every sum gets 0
@@ -691,19 +694,20 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             row_moments_and_totals<HAS_ZA>(pv, c_rg.x, c_rg.y, c_b, c_z, mk, mom, tot);
             if (vis_slot >= 0) my_slot[kk * SLOT] = t == 3 ? tot : mom;   // one ds_write_b32 per visit, 10 lanes per row
         };
-        for (int kk = 0; kk < nmax; kk += 2, lp += 2 * sizeof(wl_t)) {
+        int kk = 0;
+        for (; kk < nmax; kk += 2, lp += 2 * sizeof(wl_t)) {
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
             visit(kk, IntC<sizeof(wl_t)>());
             visit(kk + 1, IntC<2 * sizeof(wl_t)>());
         }
-        if (lane == 0) visited_all[wave] = visited;
+        if (lane == 0) walked_all[wave] = (uint32_t)min(kk, nmax);
         __syncthreads();
         // flush: the 16 lanes of a DPP row take one pair, lane b the sums of 4x4 block b (moved from the block's
         // origin to the centre of the Gaussian's box); the 22-add row reduce-scatter adds the 16 blocks up and ten
         // lanes add one value each to the Gaussian's row: sum pv {dx, dy, dx^2, dx dy, dy^2, 1} and the four
         // colour / depth totals.  The conic and opacity factors are applied by gs_preprocess_bwd.
         const int blk = tid & 15;
-        const uint64_t blk_visited = visited_all[blk >> 2];
+        const uint32_t blk_walked = walked_all[blk >> 2];
         const pos_t* blk_posmap = posmap_all[blk >> 2] + (blk & 3) * BATCH;
         const float* blk_slots = POOL > 0 ? slots + (size_t)flush_base * SLOT : slots + (size_t)blk * BSTR;
         // origin of 4x4 block blk = 4 wave + row (make_ctx)
@@ -714,10 +718,12 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         for (int r = 0; r < BATCH / 16; ++r) {
             const int j = r * 16 + (tid >> 4);
             const uint32_t pos = blk_posmap[j];
-            const bool valid = j < n && pos != (uint32_t)POS_NONE && ((blk_visited >> pos) & 1ull);
+            // block blk holds sums for pair j if the pair is in its list at a position its wave walked (POS_NONE = 255 is
+            // behind every list; pairs behind n are in no list)
+            const bool valid = pos < blk_walked;
             const uint64_t vm = __ballot(valid);
             GS_STAT(6, 1); GS_STAT(9, __popcll(vm));
-            if (vm == 0) continue;                   // wave-uniform: none of this wave's 4 pairs was visited
+            if (vm == 0) continue;                   // wave-uniform: none of this wave's 4 pairs is in a walked list
             GS_STAT(7, 1);
             const bool any = ((vm >> (lane & 48)) & 0xFFFFull) != 0;
             // lanes without a slot read the always-zero slot behind the last one

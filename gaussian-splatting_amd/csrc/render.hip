@@ -190,7 +190,6 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
     }
     __syncthreads();
     const int lane = tid & 63;
-    const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t* squ = (const uint32_t*)sq;
     int cnt[GS_ROWS] = {0, 0, 0, 0};
     if (BATCH <= 32) {
@@ -213,7 +212,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         for (int xq = 0; xq < 2; ++xq) {
             const int q = 2 * h + xq;                              // this lane's row: make_ctx's row = 2 (y half) + (x half)
             const bool hit = (xq ? hx1 : hx0) && hy && !((dead_rows >> q) & 1u);
-            const uint64_t m = __ballot(hit);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
             const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
             const int pos = __popc((h ? mhi : mlo) & lt32);
             if (hit) wl[q * (BATCH + 1) + pos] = (wl_t)(48u * (uint32_t)j);
@@ -238,8 +237,8 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
                                    hx0 && hy1 && !(dead_rows & 4u), hx1 && hy1 && !(dead_rows & 8u)};
 #pragma unroll
         for (int q = 0; q < GS_ROWS; ++q) {
-            const uint64_t m = __ballot(hit[q]);
-            const int pos = cnt[q] + __popcll(m & lt);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(hit[q]);     // (the lane mask itself; __ballot goes through a select and a compare)
+            const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (hit[q]) wl[q * (BATCH + 1) + pos] = (wl_t)(48u * (uint32_t)j);
             if (posmap && j < BATCH) posmap[q * BATCH + j] = hit[q] ? (pos_t)pos : POS_NONE;
             cnt[q] += __popcll(m);
@@ -279,7 +278,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 // bit q: all 16 lanes of DPP row q of this wave have stopped (wave-uniform)
 __device__ __forceinline__ uint32_t dead_row_mask(uint32_t P) {
-    const uint64_t st = __ballot(P == P_STOPPED);
+    const uint64_t st = __builtin_amdgcn_ballot_w64(P == P_STOPPED);
     uint32_t d = 0;
 #pragma unroll
     for (int q = 0; q < GS_ROWS; ++q) d |= (((st >> (16 * q)) & 0xFFFFull) == 0xFFFFull) ? (1u << q) : 0u;
@@ -721,7 +720,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             // block blk holds sums for pair j if the pair is in its list at a position its wave walked (POS_NONE = 255 is
             // behind every list; pairs behind n are in no list)
             const bool valid = pos < blk_walked;
-            const uint64_t vm = __ballot(valid);
+            const uint64_t vm = __builtin_amdgcn_ballot_w64(valid);
             GS_STAT(6, 1); GS_STAT(9, __popcll(vm));
             if (vm == 0) continue;                   // wave-uniform: none of this wave's 4 pairs is in a walked list
             GS_STAT(7, 1);

@@ -35,7 +35,7 @@ STAGE = {"render_bwd": ["render_bwd_kernel"], "render_fwd": ["render_fwd_kernel"
          "scan_tiles": ["scan_reduce_rect_kernel", "scan_sums_kernel", "scan_final_rect_kernel", "scan_reduce_kernel", "scan_final_kernel"],
          "radix_sort_pass": ["radix_hist_kernel", "radix_scatter_kernel"]}
 # mean issue cost of the visit loops' instruction mix (profiles/r1f_valu_issue_rates.txt; counted in the ISA)
-ISSUE = {"render_bwd": float(os.environ.get("GS_BWD_ISSUE_CYCLES", "3.67")), "render_fwd": 3.57}
+ISSUE = {"render_bwd": float(os.environ.get("GS_BWD_ISSUE_CYCLES", "3.64")), "render_fwd": 3.57}
 # Several instantiations of one kernel can appear in a trace (the bench also renders once without a backward to follow:
 # preprocess_fwd_kernel<3, true, false>).  A stage counts each kernel name once: the instantiation the timed path
 # launches, i.e. the one with the most calls in the kernel trace.

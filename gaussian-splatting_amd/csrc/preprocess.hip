@@ -791,7 +791,7 @@ int launch_bwd(int mode, int N, int K, int H, int W, const float* view, const fl
 
 int check_common(int N, int K, int deg, int H, int W, const void* means3D, const void* scales,
                  const void* rots, const void* cov6, const void* shs, const void* colors) {
-    GS_REQUIRE(N >= 0, "N must be >= 0");
+    GS_REQUIRE(N >= 0 && N < (1 << 30), "N = %d outside 0..2^30-1 (the tile kernels keep 4 x the Gaussian index in 32 bits)", N);
     GS_REQUIRE(H > 0 && W > 0 && H < 65536 && W < 65536, "image size %dx%d outside 1..65535", W, H);
     GS_REQUIRE(deg >= 0 && deg <= 3, "sh_degree %d outside 0..3", deg);
     GS_REQUIRE(N == 0 || means3D, "means3D is null");

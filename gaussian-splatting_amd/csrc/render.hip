@@ -181,7 +181,7 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
             // taken about): formed once per pair here instead of once per lane and flush round
             const uint32_t rx = __float_as_uint(p1.w), ry = __float_as_uint(p2.w);
             const uint32_t cx = ((rx & 0xFFFFu) + ((rx >> 16) - 1u)) >> 1, cy = ((ry & 0xFFFFu) + ((ry >> 16) - 1u)) >> 1;
-            sid[tid] = make_uint2(id, cx | (cy << 16));
+            sid[tid] = make_uint2(id << 2, cx | (cy << 16));     // 4 x index: the flush turns it into a row address with one shift-add
         }
         to_lds_form(p0, p1, p2);
         sq[3 * tid] = p0;
@@ -447,12 +447,6 @@ __device__ __forceinline__ float row_reduce_scatter10(const float (&v)[10], int 
     return t == 0 ? p0 : (t == 1 ? p1 : p2);
 }
 
-// gradient row (GS_GRAD_ROW = 16 floats = 64 bytes, see gsplat_common.h): sums 0..5 are doubles, 6..9 floats 12..15
-__device__ __forceinline__ void add_to_row(float* row, int idx, float v) {
-    if (idx < 6) atomicAdd(reinterpret_cast<double*>(row) + idx, (double)v);
-    else atomicAdd(row + 6 + idx, v);
-}
-
 // Per-visit reduction of a 4x4 block (one 16-lane DPP row, lane = 4 ly + lx) in LOCAL pixel coordinates:
 // from ONE value per lane, pv = G dL/dw, the six moments  M_ab = sum pv lx^a ly^b  (a + b <= 2), and beside them
 // the plain totals of up to four colour / depth products.  The moments about the Gaussian's mean that the gradient
@@ -551,7 +545,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     constexpr int NBLK = NW * GS_ROWS;          // 16 4x4 blocks per tile
     constexpr int SLOT = 10;                    // floats per (block, list position) slot
     __shared__ f4 sq[3 * (BATCH + 1)];
-    __shared__ uint2 sid[BATCH];                       // (Gaussian index, centre of its box as x | y << 16)
+    __shared__ uint2 sid[BATCH];                       // (4 x Gaussian index, centre of its box as x | y << 16)
     __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
     __shared__ pos_t posmap_all[NW][GS_ROWS * BATCH];
 #ifndef GS_SLOT_PAD
@@ -591,6 +585,9 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     if (t == 0) red_slot = ((bank & 1) ? 2 : 0) + 5 * (bank >> 1);
     else if (t == 1) red_slot = ((bank & 1) ? 3 : 1) + 5 * (bank >> 1);
     else if (t == 2 && !(bank & 1) && (HAS_ZA || bank == 0)) red_slot = 4 + 5 * (bank >> 1);
+    // gradient row (GS_GRAD_ROW = 16 floats = 64 bytes, see gsplat_common.h): sums 0..5 are doubles, 6..9 floats 12..15
+    static_assert(GS_GRAD_ROW == 16, "row layout");
+    char* const lane_row0 = reinterpret_cast<char*>(grad_rows) + (red_slot < 0 ? 0 : (red_slot < 6 ? 8 * red_slot : 4 * (6 + red_slot)));
     static_assert(BATCH <= 64 && BATCH % 16 == 0, "tested up to 64 pairs; the flush takes 16 pairs per round");
     // what this lane stores per visit (row_moments_and_totals): slot = [M00 M10 M20 M01 M11 M02 | c0 c1 c2 c3]
     int vis_slot = -1;
@@ -752,7 +749,11 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
             const float sum = row_reduce_scatter10<HAS_ZA>(v, t);
             if (any && red_slot >= 0) {
                 const float outv = sum;
-                add_to_row(grad_rows + (size_t)idc.x * GS_GRAD_ROW, red_slot, outv);
+                // idc.x = 4 x Gaussian index (staging): a row is 64 bytes = 16 x that (one v_lshl_add_u64); the lane's own byte
+                // offset inside a row sits in lane_row0 already
+                char* dst = lane_row0 + ((uint64_t)idc.x << 4);
+                if (red_slot < 6) atomicAdd(reinterpret_cast<double*>(dst), (double)outv);
+                else atomicAdd(reinterpret_cast<float*>(dst), outv);
             }
         }
     }

@@ -152,7 +152,7 @@ int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32
  * integer box (csrc/gsplat_common.h) -- fp64 atomics, so they do not depend on the order in which the tiles
  * arrive -- and four floats (bytes 48..63): d/d rgb, d/d depth.  The rows are an opaque hand-over to
  * gs_preprocess_bwd, which turns the moments into d/d screen mean, d/d conic and d/d opacity.
- * t_eps must equal the forward's.
+ * t_eps must equal the forward's.  Gaussian indices (point_list) must be below 2^30 (gs_preprocess_fwd rejects more).
  */
 int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const uint32_t* point_list,
                   const float* aux_rgb, const float* out_depth, const float* out_alpha,

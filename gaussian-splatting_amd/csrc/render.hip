@@ -276,6 +276,19 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 }
 template <int V> struct IntC { static constexpr int value = V; };
 
+// Barrier + "does pred hold in every lane of the workgroup?" (GS_BLOCK = 4 waves, all lanes active).  The library form,
+// __syncthreads_and, is a DPP reduction per wave, an LDS exchange and TWO barriers; here a wave's answer is one ballot,
+// lane 0 leaves it in flags[wave], and the one barrier the batch loop needs anyway publishes it.  The next call's
+// writes come after every wave has passed a later barrier (stage_and_cull's), so the reads here cannot see them.
+__device__ __forceinline__ bool block_all(bool pred, uint32_t* flags) {
+    static_assert(GS_BLOCK == 256, "four wave flags read as one 16-byte word");
+    const uint32_t wave_ok = __builtin_amdgcn_ballot_w64(!pred) == 0ull ? 1u : 0u;
+    if ((threadIdx.x & 63) == 0) flags[threadIdx.x >> 6] = wave_ok;
+    __syncthreads();
+    const uint4 f = *reinterpret_cast<const uint4*>(flags);
+    return (f.x & f.y & f.z & f.w) != 0u;
+}
+
 // bit q: all 16 lanes of DPP row q of this wave have stopped (wave-uniform)
 __device__ __forceinline__ uint32_t dead_row_mask(uint32_t P) {
     const uint64_t st = __builtin_amdgcn_ballot_w64(P == P_STOPPED);
@@ -313,6 +326,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     }
     __shared__ f4 sq[3 * (BATCH + 1)];
     __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
+    __shared__ __attribute__((aligned(16))) uint32_t wave_flags[NW];
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int lane = threadIdx.x & 63;
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_fwd_kernel(
     uint32_t P = c.inside ? ((uint32_t)c.px | (uint32_t)c.py << 16) : P_STOPPED;
     write_pad_record(sq, BATCH);
     for (uint32_t base = range.x; base < range.y; base += BATCH) {
-        if (__syncthreads_and(P == P_STOPPED)) break;
+        if (block_all(P == P_STOPPED, wave_flags)) break;
         const int n = min((int)(range.y - base), BATCH);
         const int nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, nullptr, wl, nullptr,
                                                dead_row_mask(P));
@@ -557,6 +571,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     __shared__ float slots[NSLOTF + SLOT];             // plain stores, one 40-byte slot per row visit (+ a zero slot)
     __shared__ uint32_t row_cnt[NBLK];                 // POOL: list length of every 4x4 block, this batch
     __shared__ uint32_t row_base[POOL > 0 ? NW : 1][NBLK];   // POOL: first slot of every block (a private copy per wave)
+    __shared__ __attribute__((aligned(16))) uint32_t wave_flags[NW];
     __shared__ uint32_t walked_all[NW];              // list positions the wave walked this batch (all of them unless every pixel stopped)
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
@@ -603,7 +618,7 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     uint32_t flush_base = 0;                            // POOL: first slot of the block this lane flushes (tid & 15)
     int n = 0;
     for (uint32_t base = range.x; base < range.y; base += n) {
-        if (__syncthreads_and(P == P_STOPPED)) break;
+        if (block_all(P == P_STOPPED, wave_flags)) break;
         n = min((int)(range.y - base), BATCH);
         int nmax;
         if (POOL > 0) {

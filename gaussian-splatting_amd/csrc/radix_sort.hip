@@ -170,13 +170,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
             wave_cnt[w][tid] = run;
             run += c;
         }
-        uint32_t incl = run, gincl = total;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t t = __shfl_up(incl, dlt, 64);
-            const uint32_t g = __shfl_up(gincl, dlt, 64);
-            if (lane >= dlt) { incl += t; gincl += g; }
-        }
+        const uint32_t incl = gs_wave_incl_scan(run), gincl = gs_wave_incl_scan(total);
         if (lane == 63) { scan_tmp[0][wave] = incl; scan_tmp[1][wave] = gincl; }
         __syncthreads();
         uint32_t wbase = 0, gbase = 0;

@@ -13,14 +13,7 @@ constexpr int SCAN_ITEMS = 16;  // consecutive elements per lane
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int SCAN_FUSE_MAX = 4096;   // workgroups (16.8 M Gaussians) up to which the final pass sums the block totals itself
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int) { return gs_wave_incl_scan(v); }
 
 // exclusive scan of one value per lane across the workgroup; returns (exclusive prefix, block total)
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total) {
@@ -140,7 +133,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_rect_kernel(const uin
         const long long idx = base + j * 64;
         const uint32_t incl = wave_incl_scan(v[j], lane);
         if (idx < n) out[idx] = run + incl - v[j];
-        run += __shfl(incl, 63, 64);
+        run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
 }
 

@@ -31,16 +31,21 @@ constexpr int RS_RADIX = 256;
 constexpr int RS_GROUP = 32;                    // workgroups per grp row
 constexpr int RS_MAX_PASSES = 4;
 
-// lanes of this wave holding the same NBITS-bit digit (only among `valid` lanes)
+// lanes of this wave holding the same NBITS-bit digit (only among `valid` lanes).  Per digit bit: x = the bit spread over
+// a register (0 / ~0, one v_bfe_i32), m = the ballot of it (one v_cmp), and peers &= ~(m ^ x) -- lanes whose bit equals
+// mine -- as one v_bitop3_b32 per half: four instructions per bit where the select-based form took nine.
 template <int NBITS>
-__device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid) {
-    uint64_t peers = __ballot(valid);
+__device__ __forceinline__ uint64_t match_digit(uint32_t key, int shift, bool valid) {
+    const uint64_t v = __builtin_amdgcn_ballot_w64(valid);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
 #pragma unroll
     for (int b = 0; b < NBITS; ++b) {
-        const bool bit = (digit >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
+        const uint32_t x = (uint32_t)__builtin_amdgcn_sbfe((int)key, (uint32_t)(shift + b), 1u);   // bit shift + b of the key
+        const uint64_t m = __builtin_amdgcn_ballot_w64(x != 0u);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m, x, 0x90);           // lo & ~(m ^ x)
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m >> 32), x, 0x90);
     }
+    const uint64_t peers = ((uint64_t)hi << 32) | lo;
     return valid ? peers : 0ull;
 }
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         const long long idx = base + it * 64 + lane;
         const bool valid = idx < D;
         const uint32_t d = (key[it] >> shift) & mask;
-        const uint64_t peers = match_digit<NBITS>(d, valid);
+        const uint64_t peers = match_digit<NBITS>(key[it], shift, valid);
         uint32_t prior = 0;
         if (valid) prior = my_cnt[d];  // every peer reads the same counter ...
         __builtin_amdgcn_wave_barrier();
@@ -256,7 +261,10 @@ static int sort_pairs_impl(long long D, const uint32_t* count_dev, int bit_begin
     hipLaunchKernelGGL((radix_scatter_kernel<NB>), dim3(nblocks), dim3(RS_THREADS), 0, stream, ks, vs, kd, vd, D, \
                        count_dev, shift, mask, blk, grp)
         switch (nbits) {
-            case 1: case 2: case 3: case 4: GS_SCATTER(4); break;
+            case 1: GS_SCATTER(1); break;      // exact widths: the ranking reads the key's bits [shift, shift + NBITS) unmasked
+            case 2: GS_SCATTER(2); break;
+            case 3: GS_SCATTER(3); break;
+            case 4: GS_SCATTER(4); break;
             case 5: GS_SCATTER(5); break;
             case 6: GS_SCATTER(6); break;
             case 7: GS_SCATTER(7); break;

@@ -309,7 +309,8 @@ def test_optimistic_binning_equals_exact_and_recovers_from_overflow(dgr):
 
 
 @pytest.mark.parametrize("n,bits,use_count", [(0, 32, False), (1, 32, False), (5000, 32, False), (70000, 13, False),
-                                              (70000, 13, True), (300000, 32, True), (4097, 5, False)])
+                                              (70000, 13, True), (300000, 32, True), (4097, 5, False)] +
+                         [(20000, b, False) for b in (1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 14, 15, 16)])   # every last-pass width
 def test_sort_pairs_stable_on_bit_range(n, bits, use_count):
     """gs_sort_pairs through the C-ABI against numpy's stable argsort on the masked key; with use_count
     the pair count comes from device memory and the buffers are larger than it (capacity)."""

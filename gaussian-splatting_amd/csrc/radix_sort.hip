@@ -143,7 +143,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     uint32_t val[RS_ITEMS];
     uint32_t rank[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
-    volatile uint32_t* my_cnt = wave_cnt[wave];
+    // volatile (every peer reads the counter before the first one bumps it) AND explicitly in the LDS address space: through
+    // a generic volatile pointer the compiler emits flat loads / stores with system scope for these 32 accesses per lane
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_counter_t;
+    lds_counter_t* my_cnt = (lds_counter_t*)wave_cnt[wave];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
         const long long idx = base + it * 64 + lane;

@@ -8,7 +8,10 @@ tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out
 BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-mode --no-next-rows"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- $BENCH > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_trace.err
+# the trace runs more steps than the counter passes: the first launches of a process are slower (render_bwd 0.70 -> 0.65 ms over
+# its first ten launches), and the per-kernel mean of this trace is what bench.py's event time is compared with
+TRACE_BENCH="python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-exact-mode --no-next-rows"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- $TRACE_BENCH > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_trace.err
 echo trace done
 i=0
 for P in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" \

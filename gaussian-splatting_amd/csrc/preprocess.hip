@@ -33,6 +33,8 @@ constexpr float SH_C3_5 = 1.445305721320277f;
 constexpr float SH_C3_6 = -0.5900435899266435f;
 
 struct Geom {
+    float pos[3];        // the mean as loaded (project_mean)
+    float scl[3], quat[4];   // scales and rotation as loaded (project_cov, scale/rotation path)
     float cam[3];
     float clip[4];
     float mx, my;
@@ -54,6 +56,7 @@ __device__ __forceinline__ void project_mean(int i, int H, int W, const float* _
                                              const float* __restrict__ proj, const float* __restrict__ means3D, Geom& g) {
 #pragma clang fp contract(off)
     const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+    g.pos[0] = px; g.pos[1] = py; g.pos[2] = pz;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
         g.cam[r] = view[4 * r] * px + view[4 * r + 1] * py + view[4 * r + 2] * pz + view[4 * r + 3];
@@ -87,6 +90,7 @@ __device__ __forceinline__ void project_cov(int i, int H, int W, int row_b, int 
         g.S[2][0] = c[2]; g.S[2][1] = c[4]; g.S[2][2] = c[5];
     } else {
         const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+        g.quat[0] = q.x; g.quat[1] = q.y; g.quat[2] = q.z; g.quat[3] = q.w;
         const float r = q.x, x = q.y, y = q.z, z = q.w;
         g.R[0][0] = 1.0f - 2.0f * (y * y + z * z);
         g.R[0][1] = 2.0f * (x * y - r * z);
@@ -98,6 +102,7 @@ __device__ __forceinline__ void project_cov(int i, int H, int W, int row_b, int 
         g.R[2][1] = 2.0f * (y * z + r * x);
         g.R[2][2] = 1.0f - 2.0f * (x * x + y * y);
         const float s0 = scales[3 * (size_t)i], s1 = scales[3 * (size_t)i + 1], s2 = scales[3 * (size_t)i + 2];
+        g.scl[0] = s0; g.scl[1] = s1; g.scl[2] = s2;
         float M[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -471,13 +476,22 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     if (drawn) {
-        Geom g;
-        if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
+        // The gradient row, the opacity and the side-table row are requested BEFORE the projection is recomputed, so that
+        // they travel while it runs (requested after it, the kernel waited for memory three times in a row: radius,
+        // geometry, rows).
         // row = 6 doubles (moments of pv about the box centre) + floats 12..15 (rgb, depth): gsplat_common.h
         static_assert(GS_GRAD_ROW == 16, "row layout");
         const float4* row = grad_rows + (GS_GRAD_ROW / 4) * (size_t)i;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 r0 = PART != 2 ? row[0] : z4, r1 = PART != 2 ? row[1] : z4, r2 = PART != 2 ? row[2] : z4, r3 = row[3];
+        const float opacity_i = PART != 2 ? opacities[i] : 0.0f;
+        float4 j0 = z4, j1 = z4, j2 = z4;
+        if (JAC) {
+            const float4* jp = sh_jac + 3 * (size_t)i;
+            j0 = jp[0]; j1 = jp[1]; j2 = jp[2];
+        }
+        Geom g;
+        if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
         const auto dbl = [](float lo, float hi) {
             return __hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo));
         };
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         if (PART != 2) {
             // moments of q = opacity * pv about the mean, from the moments of pv about the box centre (double: the
             // shift can be thousands of pixels for a splat whose mean is far off screen)
-            const double op = (double)opacities[i];
+            const double op = (double)opacity_i;
             const double M0 = dbl(r2.z, r2.w);
             const double ex = (double)((g.xmin + g.xmax - 1) >> 1) - (double)g.mx;
             const double ey = (double)((g.ymin + g.ymax - 1) >> 1) - (double)g.my;
@@ -506,7 +520,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         gop = d_op;
         gm2[0] = d_mx;
         gm2[1] = d_my;
-        const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+        float px, py, pz;            // (the projection has loaded the mean already: a second load here was a second wait)
+        if (PART != 2) { px = g.pos[0]; py = g.pos[1]; pz = g.pos[2]; }
+        else { px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2]; }
         // ---- colour
         if (colors_precomp) {
             gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
@@ -522,8 +538,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             float ddir[3] = {0.f, 0.f, 0.f};
             if (JAC) {
                 // W = d colour / d dir and the clamp mask as the forward left them
-                const float4* jp = sh_jac + 3 * (size_t)i;
-                const float4 j0 = jp[0], j1 = jp[1], j2 = jp[2];
                 const float Wm[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
                 const uint32_t pass = __float_as_uint(j2.y);
 #pragma unroll
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             gc6[0] = dS[0][0]; gc6[1] = dS[0][1] + dS[1][0]; gc6[2] = dS[0][2] + dS[2][0];
             gc6[3] = dS[1][1]; gc6[4] = dS[1][2] + dS[2][1]; gc6[5] = dS[2][2];
         } else {
-            const float s[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+            const float s[3] = {g.scl[0], g.scl[1], g.scl[2]};     // as the projection loaded them: no second load, no second wait
             float dR[3][3];
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2) {
@@ -687,8 +701,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 }
                 gs[b2] = acc;
             }
-            const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-            const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+            const float r = g.quat[0], qx = g.quat[1], qy = g.quat[2], qz = g.quat[3];
             gq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
             gq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - r * dR[1][2] + qz * dR[2][0] + r * dR[2][1] - 2.0f * qx * dR[2][2]);
             gq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + r * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);

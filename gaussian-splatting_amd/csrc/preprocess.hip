@@ -329,9 +329,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // computed (issued after it, the kernel paid two memory latencies in a row: 0.222 -> 0.203 ms).
     constexpr int NBH = (DEG + 1) * (DEG + 1);
     float sh_h[NBH * 3 + 3];
+    float opacity_i = 0.0f;
     if (in_range) {
         project_mean(i, H, W, view, proj, means3D, g);
-        if (!colors_precomp && mean_near_frame(g, H, W)) load_sh<NBH, VEC4>(shs, i, K, sh_h);
+        if (mean_near_frame(g, H, W)) {
+            if (!colors_precomp) load_sh<NBH, VEC4>(shs, i, K, sh_h);
+            opacity_i = opacities[i];      // only copied into the record at the very end: loaded there, it was one more wait
+        }
         project_cov(i, H, W, row_b, row_e, proj, scales, rots, cov6, g);
         drawn = g.drawn;
         radii[i] = g.radius;
@@ -369,9 +373,9 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         constexpr int NB = (DEG + 1) * (DEG + 1);
         float* sh = sh_h;       // loaded above (a drawn Gaussian has passed mean_near_frame)
         float b[NB];
-        float dx = means3D[3 * (size_t)i] - campos[0];
-        float dy = means3D[3 * (size_t)i + 1] - campos[1];
-        float dz = means3D[3 * (size_t)i + 2] - campos[2];
+        float dx = g.pos[0] - campos[0];     // the mean as project_mean loaded it (a second load here was a second wait)
+        float dy = g.pos[1] - campos[1];
+        float dz = g.pos[2] - campos[2];
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz) + 1e-7f;
         dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
         sh_basis<DEG>(dx, dy, dz, b);
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         const uint32_t rx = (uint32_t)g.xmin | ((uint32_t)g.xmax << 16);
         const uint32_t ry = (uint32_t)g.ymin | ((uint32_t)g.ymax << 16);
         st[3 * lane] = make_float4(g.mx, g.my, g.ca, g.cb);
-        st[3 * lane + 1] = make_float4(g.cd, opacities[i], g.cam[2], __uint_as_float(rx));
+        st[3 * lane + 1] = make_float4(g.cd, opacity_i, g.cam[2], __uint_as_float(rx));
         st[3 * lane + 2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(ry));
     }
     write_rows(splat);

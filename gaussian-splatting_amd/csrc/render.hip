@@ -16,9 +16,10 @@
 // and compacts one list per row.  A 4x4 block wastes far fewer lanes on a ~13 px box than an 8x8
 // sub-tile does (63 % of the lane slots are inside the box instead of 43 %), and the loop length of
 // a wave is the longest of its four lists: 0.68 of the 8x8 hit count on the benchmark scene.  The
-// row's list entry (record byte offset, one ds_read_b32 with four distinct addresses) and the
-// 48-byte record (three ds_read_b128) are plain per-lane LDS reads; shorter lists are padded with
-// a record no lane is inside, so there is no per-visit bounds test.  (History: 8x8 per wave with
+// row's list entry (16-bit record byte offset, one hand-issued ds_read_u16 with four distinct addresses,
+// one visit ahead) and the 48-byte record (three ds_read_b128) are per-lane LDS reads; shorter lists are
+// padded with a record no lane is inside, so there is no per-visit bounds test, and the loops take two
+// visits per trip.  (History: 8x8 per wave with
 // the hit index through v_readlane; before that b96/b32/u8 record reads, 26 LDS cycles per
 // Gaussian; scalar s_load of the records is slower: the scalar cache cannot stream misses.)
 // A lane stops once its transmittance 1 - A drops below t_eps, a wave when all its lanes stopped
@@ -37,10 +38,11 @@
 // each into the 40-byte LDS slot of (4x4 block, list position) -- plain stores into a slot pool shared by the tile's 16
 // blocks, so that a 64-pair batch fits the LDS of 6 workgroups per CU; after the batch the 16 lanes of a
 // DPP row take one pair each, lane b reads block b's slot and moves its moments to the centre of the Gaussian's
-// box, a 22-add reduce-scatter adds the 16 blocks up, and one row-shaped atomic per (tile, Gaussian) goes into
-// that Gaussian's 64-byte gradient row (six geometric sums as fp64 atomics: gsplat_common.h).
+// box (formed once per pair at staging), a 22-add reduce-scatter adds the 16 blocks up, and one row-shaped atomic
+// per (tile, Gaussian) goes into that Gaussian's 64-byte gradient row (six geometric sums as fp64 atomics:
+// gsplat_common.h).  A block holds sums for a pair iff the pair's list position was walked by the block's wave.
 //
-// Bound: VALU issue (~21 instructions per visit forward, ~50 backward); HBM traffic is the record
+// Bound: VALU issue (~20 instructions per visit forward, 47 backward); HBM traffic is the record
 // gather per (tile, Gaussian) pair plus 28 / 44 bytes per pixel.
 #include "gsplat_common.h"
 

@@ -83,8 +83,6 @@ __device__ __forceinline__ uint32_t gs_depth_key_desc(float z) {
     return ~asc;
 }
 
-// Tiles overlapped by a packed box (rect_x = x_min | x_max << 16, rect_y likewise; half-open, pixels)
-// inside the band of tile rows [row_b, row_e).  An all-zero box (Gaussian not drawn) has no tiles.
 // Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (shifts by 1, 2, 4, 8 inside every 16-lane row, then
 // lane 15 of a row into the next row, lane 31 into the upper half): no LDS crossbar round trips (__shfl_up is a
 // ds_bpermute per step -- six dependent ~100-cycle hops per scan in kernels that are latency-bound as it is).
@@ -98,6 +96,8 @@ __device__ __forceinline__ uint32_t gs_wave_incl_scan(uint32_t v) {
     return v;
 }
 
+// Tiles overlapped by a packed box (rect_x = x_min | x_max << 16, rect_y likewise; half-open, pixels)
+// inside the band of tile rows [row_b, row_e).  An all-zero box (Gaussian not drawn) has no tiles.
 struct GsTileSpan { int tx0, tx1, ty0, ty1; };
 __device__ __forceinline__ uint32_t gs_tile_span(uint32_t rect_x, uint32_t rect_y, int row_b, int row_e, GsTileSpan& t) {
     const int xmin = rect_x & 0xFFFF, xmax = rect_x >> 16, ymin = rect_y & 0xFFFF, ymax = rect_y >> 16;

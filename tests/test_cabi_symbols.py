@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_housekeeping_calls_work_without_a_gpu():
-    lib = importlib.import_module("gaussian-splatting_amd._lib").load()
+    lib_mod = lambda: importlib.import_module("gaussian-splatting_amd._lib")  # noqa: E731
+    lib = lib_mod().load()
     assert lib.gs_version() >= 100
     assert lib.gs_tile_size() == 16
     assert lib.gs_grad_row_floats() == 16
@@ -42,6 +43,11 @@ def test_housekeeping_calls_work_without_a_gpu():
     # argument errors are reported through the return code + gs_last_error, never a crash
     rc = lib.gs_identify_tile_ranges(-1, None, 0, None, None, None)
     assert rc == -1 and b"bad arguments" in lib.gs_last_error()
+    # the tile kernels keep 4 x the Gaussian index in 32 bits: 2^30 Gaussians and more are refused before any launch
+    import ctypes
+    rest = [None if t is ctypes.c_void_p else 0 for t in lib_mod().PROTOTYPES["gs_preprocess_fwd"][1][5:]]
+    rc = lib.gs_preprocess_fwd(1 << 30, 16, 3, 840, 1297, *rest)
+    assert rc == -1 and b"2^30" in lib.gs_last_error()
 
 
 def test_no_oracle_in_product_path():

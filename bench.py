@@ -61,15 +61,11 @@ COUNTERS_NOTE = [None]
 
 
 def csrc_sha():
-    """Hash of the kernel sources the in-tree library is built from (the stamp of profiles/counters.json)."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the kernel sources the in-tree library is built from (the stamp of profiles/counters.json; the library
+    reports the hash it was compiled from as gs_source_sha())."""
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting_amd", "csrc"))
+    from source_sha import source_sha
+    return source_sha()
 
 
 def load_counters(config, t_eps):

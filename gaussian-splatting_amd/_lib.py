@@ -32,6 +32,7 @@ class GsPlyLayout(C.Structure):
 PROTOTYPES = {
     "gs_version": (_i, []),
     "gs_last_error": (C.c_char_p, []),
+    "gs_source_sha": (C.c_char_p, []),
     "gs_tile_size": (_i, []),
     "gs_grad_row_floats": (_i, []),
     "gs_sh_jac_row_floats": (_i, []),
@@ -59,6 +60,7 @@ PROTOTYPES = {
 }
 
 _lib = None
+ABI_VERSION = 300     # GS_ABI_VERSION of the include/gsplat.h these prototypes were written against
 
 
 def load():
@@ -75,6 +77,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    got = int(lib.gs_version())
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports ABI version {got}, this binding was written against {ABI_VERSION} "
+                          "(include/gsplat.h GS_ABI_VERSION): rebuild the library from this tree")
     _lib = lib
     return lib
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long cap
         const long long c = (long long)*count_dev;
         D = c < cap ? c : cap;
     }
-    const uint32_t nt = (uint32_t)num_tiles;      // a key that is no tile id (never emitted by gs_duplicate_with_keys) writes nothing
+    const uint32_t nt = (uint32_t)num_tiles;
     const long long wg0 = (long long)blockIdx.x * (256 * TR_ITEMS);
     if (wg0 >= D && !(D == 0 && blockIdx.x == 0)) return;      // workgroup-uniform
     if (threadIdx.x == 0) nbig = 0;
@@ -87,16 +87,21 @@ __global__ __launch_bounds__(256) void identify_tile_ranges_kernel(long long cap
                 for (int j = 0; j < TR_ITEMS; ++j) k[j + 1] = i0 + j < D ? keys[i0 + j] : 0u;
             }
             k[0] = i0 > 0 ? keys[i0 - 1] : 0u;
-            if (i0 == 0 && k[1] < nt) {
+            // A key that is no tile id (never emitted by gs_duplicate_with_keys; sorted, so only at the end of the list) owns no
+            // entry, but the table is still written in full: such keys count as one tile BEHIND the table, so the last valid
+            // tile is closed where they begin and every tile behind it is cleared.
+#pragma unroll
+            for (int j = 0; j <= TR_ITEMS; ++j) k[j] = k[j] < nt ? k[j] : nt;
+            if (i0 == 0) {
                 clear_between(-1, k[1]);
-                ranges[k[1]].x = 0u;
+                if (k[1] < nt) ranges[k[1]].x = 0u;
             }
 #pragma unroll
             for (int j = 0; j < TR_ITEMS; ++j) {
                 const long long i = i0 + j;
-                if (i < D && i > 0 && k[j] != k[j + 1] && k[j + 1] < nt) {   // (sorted tile ids: k[j] < k[j + 1] < nt)
+                if (i < D && i > 0 && k[j] != k[j + 1] && k[j] < nt) {   // (sorted tile ids: k[j] < k[j + 1] <= nt)
                     ranges[k[j]].y = (uint32_t)i;
-                    ranges[k[j + 1]].x = (uint32_t)i;
+                    if (k[j + 1] < nt) ranges[k[j + 1]].x = (uint32_t)i;
                     clear_between(k[j], k[j + 1]);
                 }
                 if (i == D - 1 && k[j + 1] < nt) {
@@ -134,7 +139,8 @@ extern "C" int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, i
     GS_REQUIRE(D >= 0 && num_tiles > 0 && ranges, "bad arguments");
     GS_REQUIRE(D == 0 || keys, "null keys");
     GS_REQUIRE(((uintptr_t)keys & 15) == 0 && ((uintptr_t)ranges & 7) == 0, "keys must be 16-byte, ranges 8-byte aligned");
-    // keys above num_tiles - 1 would be written outside the table: the caller's keys are tile ids by construction
+    // keys above num_tiles - 1 own no entry (the kernel treats them as one tile behind the table); the caller's keys are tile
+    // ids by construction
     const long long per_wg = 256 * TR_ITEMS;
     const long long nwg = D > 0 ? (D + per_wg - 1) / per_wg : 1;
     hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, D, count_dev, keys, num_tiles,

@@ -1,5 +1,6 @@
 // C-ABI housekeeping: version, last-error string.
 #include "gsplat_common.h"
+#include "../../include/gsplat.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -17,7 +18,12 @@ void gs_set_error(const char* fmt, ...) {
 
 extern "C" const char* gs_last_error(void) { return g_err; }
 
-extern "C" int gs_version(void) { return 100; }  // 0.1.0
+extern "C" int gs_version(void) { return GS_ABI_VERSION; }
+
+#ifndef GS_SOURCE_SHA
+#define GS_SOURCE_SHA "unknown"
+#endif
+extern "C" const char* gs_source_sha(void) { return GS_SOURCE_SHA; }
 
 extern "C" int gs_tile_size(void) { return GS_TILE; }
 

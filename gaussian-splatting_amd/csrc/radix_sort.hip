@@ -341,6 +341,10 @@ extern "C" int gs_sort_pairs_static(long long D, const uint32_t* count_dev, int 
     void* ws = nullptr;
     const int rc = scratch_for_current_device(&ws);
     if (rc != GS_OK) return rc;
+    if (D == 0) {      // the documented set-up call (first call per device, outside any stream capture): nothing to sort
+        *result_in_b = 0;
+        return GS_OK;
+    }
     // the tables are rewritten (blk) or cleared (grp) by every call: nothing of the previous call is read
     return sort_pairs_impl(D, count_dev, bit_begin, bit_end, keys_a, vals_a, keys_b, vals_b, ws, SCRATCH_BYTES,
                            result_in_b, stream_);

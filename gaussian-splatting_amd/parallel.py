@@ -242,7 +242,6 @@ class _RasterizeSharded(torch.autograd.Function):
             image, depth, alpha, aux, rows = R.render_forward(mine, splat, state.ranges, state.point_list, need_grad,
                                                               t_eps, band)
         ctx.rows = rows
-        ctx.sh_jac = jac
         ctx.set_materialize_grads(False)
         ctx.views, ctx.t_eps, ctx.counts, ctx.group, ctx.band = views, float(t_eps), list(counts), group, band
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
@@ -252,6 +251,9 @@ class _RasterizeSharded(torch.autograd.Function):
         if aux is not None:
             saved.append(aux)
         ctx.has_aux = aux is not None
+        ctx.has_jac = jac is not None        # saved like the rest: freed with the graph (rasterizer._RasterizeGaussians)
+        if ctx.has_jac:
+            saved.append(jac)
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(radii)
         return image, radii, depth, alpha
@@ -267,6 +269,7 @@ class _RasterizeSharded(torch.autograd.Function):
         if not ctx.has_aux:
             raise RuntimeError("backward called but no input required grad in forward")
         aux = rest.pop(0)
+        sh_jac = rest.pop(0) if ctx.has_jac else None
         group, views, counts = ctx.group, ctx.views, ctx.counts
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         dev = means3D.device
@@ -278,7 +281,7 @@ class _RasterizeSharded(torch.autograd.Function):
             rows = R.render_backward(views[rank], splat, ranges, point_list, aux, depth, alpha, g_image, g_depth,
                                      g_alpha, rows, ctx.t_eps, ctx.band)
             total = int(sum(counts))
-            # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, 12)
+            # 4. every Gaussian's sums go back to its owner: (view, local Gaussian, one 64-byte gradient row of 16 floats)
             rows_mine = torch.empty((world * max(n, 1), R.grad_row_floats()), dtype=torch.float32, device=dev)[:world * n]
             with _stage("exchange_bwd"):
                 w_rows = _all_to_all_rows(rows_mine, rows[:total], [n] * world, counts, group, True)
@@ -297,7 +300,7 @@ class _RasterizeSharded(torch.autograd.Function):
                 g = R.preprocess_backward(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
                                           colors_precomp, radii[v], rows[off:off + n] if v == rank else rows_mine[v], needs,
                                           (n, 3) if per_view_means2D else None, accumulate_into=acc,
-                                          sh_jac=None if ctx.sh_jac is None else ctx.sh_jac[v])
+                                          sh_jac=None if sh_jac is None else sh_jac[v])
                 if per_view_means2D and needs[1]:
                     g_m2d[v] = g[1]
                 acc = g
@@ -321,7 +324,7 @@ class SplatExchange:
       forward   rank r projects its shard into every rank's view (gs_preprocess_fwd, `world` launches on
                 N/world Gaussians each) and one all-to-all hands every renderer the 48-byte splat records,
                 depth keys and boxes of all N Gaussians for its view (60 B per Gaussian and view);
-      backward  the renderer's 48-byte gradient rows (the ten per-Gaussian sums of render_bwd) go back to
+      backward  the renderer's 64-byte gradient rows (the ten per-Gaussian sums of render_bwd) go back to
                 the owners in one all-to-all, and each owner runs gs_preprocess_bwd per view on its shard.
 
     124 B per Gaussian and view, all of it direct peer-to-peer traffic -- the pattern the fully connected
@@ -414,7 +417,6 @@ class _RasterizeReplicated(torch.autograd.Function):
             image, depth, alpha, aux, rows = R.render_forward(settings, state.splat, state.ranges, state.point_list,
                                                               need_grad, t_eps, band)
         ctx.rows, ctx.settings, ctx.t_eps, ctx.band, ctx.owner = rows, settings, float(t_eps), band, owner
-        ctx.sh_jac = state.sh_jac
         ctx.set_materialize_grads(False)
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
@@ -423,6 +425,9 @@ class _RasterizeReplicated(torch.autograd.Function):
         ctx.has_aux = aux is not None
         if aux is not None:
             saved.append(aux)
+        ctx.has_jac = state.sh_jac is not None
+        if ctx.has_jac:
+            saved.append(state.sh_jac)
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(state.radii)
         return image, state.radii, depth, alpha
@@ -437,6 +442,7 @@ class _RasterizeReplicated(torch.autograd.Function):
         if not ctx.has_aux:
             raise RuntimeError("backward called but no input required grad in forward")
         aux = rest.pop(0)
+        sh_jac = rest.pop(0) if ctx.has_jac else None
         owner, settings = ctx.owner, ctx.settings
         dev = means3D.device
         N = means3D.shape[0]
@@ -472,7 +478,7 @@ class _RasterizeReplicated(torch.autograd.Function):
             g_m3, g_m2, g_sh, g_col, g_op, g_sc, g_rot, g_cov = full
             if not m2d_rows:
                 g_m2 = None
-            jac = ctx.sh_jac if shs is not None else None     # (N, 12): a range is a row slice like everything else
+            jac = sh_jac if shs is not None else None     # (N, 12): a range is a row slice like everything else
             for (b, e) in bucket_ranges(N, owner.num_buckets):
                 with _stage("preprocess_bwd"):
                     R._lib.check(lib.gs_preprocess_bwd(

@@ -468,7 +468,6 @@ class _RasterizeGaussians(torch.autograd.Function):
             image, depth, alpha, aux, rows = render_forward(settings, state.splat, state.ranges, state.point_list,
                                                             need_grad, t_eps, band)
         ctx.rows = rows
-        ctx.sh_jac = state.sh_jac          # scratch of this forward/backward pair, like rows
         ctx.set_materialize_grads(False)   # unused outputs (depth, alpha) arrive as None, not as zero fills
         ctx.settings = settings
         ctx.t_eps = float(t_eps)
@@ -480,6 +479,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         if aux is not None:
             saved.append(aux)
         ctx.has_aux = aux is not None
+        # the colour side table (N x 48 B) goes with the saved tensors: autograd frees it with them after a backward that
+        # does not retain the graph, and a retained graph keeps it for the next backward
+        ctx.has_jac = state.sh_jac is not None
+        if ctx.has_jac:
+            saved.append(state.sh_jac)
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(state.radii)
         return image, state.radii, depth, alpha
@@ -496,6 +500,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if not ctx.has_aux:
             raise RuntimeError("backward called but no input required grad in forward")
         aux = rest.pop(0)
+        sh_jac = rest.pop(0) if ctx.has_jac else None
         settings = ctx.settings
         with torch.cuda.device(means3D.device):
             rows, ctx.rows = ctx.rows, None          # cleared by the forward; a second backward clears its own
@@ -503,7 +508,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                    rows, ctx.t_eps, ctx.band)
             grads = preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
                                         colors_precomp, radii, rows, ctx.needs_input_grad, ctx.means2D_shape,
-                                        sh_jac=ctx.sh_jac)
+                                        sh_jac=sh_jac)
         return (*grads, None, None, None, None)
 
 

@@ -38,8 +38,15 @@ extern "C" {
 #define GS_ERR_HIP (-2)  /* a HIP call or kernel launch failed */
 #define GS_ERR_SIZE (-3) /* size beyond a stated limit */
 
-int gs_version(void);            /* 100 = 0.1.0 */
+/* ABI version of this header.  It changes whenever an entry point's argument list, a buffer layout (splat records,
+ * gradient rows, sh_jac rows) or a precondition changes: a binding compares gs_version() with the GS_ABI_VERSION it was
+ * written against before its first call (gaussian-splatting_amd/_lib.py does) -- a mismatch means shifted arguments.
+ * 100: round 1.  200: round 2 (sh_jac arguments, 64-byte gradient rows with six doubles, gs_identify_tile_ranges writes the
+ * whole table and wants 16-byte aligned keys).  300: this header. */
+#define GS_ABI_VERSION 300
+int gs_version(void);            /* == GS_ABI_VERSION of the header the library was built from */
 const char* gs_last_error(void); /* message of this thread's last failing call */
+const char* gs_source_sha(void); /* hash of the sources this library was compiled from (csrc/source_sha.py), "unknown" outside the Makefile */
 int gs_tile_size(void);          /* 16: tile edge used by keys and ranges */
 int gs_grad_row_floats(void);    /* 16: floats (4-byte units) per per-Gaussian gradient row (see gs_render_bwd) */
 
@@ -118,14 +125,20 @@ int gs_sort_pairs(long long D, const uint32_t* count_dev, int bit_begin, int bit
  * `stream` must be the current device.  All calls on one GPU share that GPU's array: calls that overlap
  * on one GPU (two streams, two threads) race -- serialise them or use gs_sort_pairs with workspaces of
  * their own.  Every call rewrites or clears what it reads, so back-to-back calls need no clean-up.
+ * First call per device: it resolves that device's address of the array (hipGetSymbolAddress, which may
+ * load the library's code object) -- set-up work that does not belong inside a stream capture.  Make one
+ * call with D = 0 on every device beforehand (it does the set-up, launches nothing and returns GS_OK);
+ * every later call on that device only launches kernels and memsets.
  */
 long long gs_sort_pairs_static_max(void);
 int gs_sort_pairs_static(long long D, const uint32_t* count_dev, int bit_begin, int bit_end, uint32_t* keys_a,
                          uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int* result_in_b, void* stream);
 /* ranges[2t], ranges[2t+1] = [start, end) of tile t in the sorted list (0,0 when empty); count_dev as
- * in gs_sort_pairs.  keys = tile ids < num_tiles in ascending order (16-byte aligned; a key >= num_tiles
- * writes nothing).  Every entry of `ranges` (8-byte aligned) is written by the call -- the entries of empty
- * tiles too, by whoever sees the keys on either side of them -- so the table needs no clearing. */
+ * in gs_sort_pairs.  keys = tile ids < num_tiles in ascending order (16-byte aligned).  Every entry of
+ * `ranges` (8-byte aligned) is written by the call -- the entries of empty tiles too, by whoever sees the
+ * keys on either side of them -- so the table needs no clearing.  Keys >= num_tiles (none are emitted by
+ * gs_duplicate_with_keys; sorted, they can only end the list) own no entry: the last valid tile ends where
+ * they begin and the tiles behind it come out empty. */
 int gs_identify_tile_ranges(long long D, const uint32_t* count_dev, int num_tiles, const uint32_t* keys,
                             uint32_t* ranges, void* stream);
 

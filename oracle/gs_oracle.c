@@ -86,6 +86,17 @@ void gso_set_threads(int n) {
 #endif
 }
 
+/*
+ * Stop threshold of the HIP path's switchable deviation (NOT in the reference, which never stops: :429-440).
+ * A pixel whose transmittance 1 - alpha_acc has dropped to <= t_eps composites nothing further, in the forward
+ * and in the derivative alike (the backward is then the exact gradient of the truncated forward).  0 (the
+ * default) restates the reference: at 0 a skipped Gaussian has alpha = w * 0 anyway.  Kept as a double so that
+ * the float64 build compares against the same number.
+ */
+static double g_t_eps = 0.0;
+void gso_set_t_eps(double t) { g_t_eps = t > 0.0 ? t : 0.0; }
+double gso_get_t_eps(void) { return g_t_eps; }
+
 /* SH basis of eval_sh (utils/sh_utils.py:64-94) for direction (x,y,z); nb = (deg+1)^2 */
 static void sh_basis(int deg, float x, float y, float z, float *b) {
     b[0] = C0;
@@ -454,6 +465,7 @@ int gso_render_forward(int N, int H, int W, const float *bg, const float *xy, co
     bands_t B;
     if (build_bands(H, V, order, rect, &B)) return -1;
     const size_t HW = (size_t)H * W;
+    const float t_eps = (float)g_t_eps;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B.nb; ++b) {
         const int y0 = b * BAND, y1 = (y0 + BAND < H) ? y0 + BAND : H;
@@ -480,6 +492,7 @@ int gso_render_forward(int N, int H, int W, const float *bg, const float *xy, co
                     const float power = -((ca * dx * dx + bc * dx * dy) + cd * dy * dy) * 0.5f;
                     const float w = expf(power) * op;
                     const size_t p = (size_t)y * W + x;
+                    if (t_eps > 0.0f && 1.0f - out_alpha[p] <= t_eps) continue; /* stopped (deviation, see gso_set_t_eps) */
                     const float alpha = w * (1.0f - out_alpha[p]);
                     out_image[p] += alpha * cr;
                     out_image[HW + p] += alpha * cg;
@@ -523,6 +536,8 @@ int gso_render_backward(int N, int H, int W, const float *xy, const float *depth
     double *acc = (double *)calloc((size_t)N * 10 + 1, sizeof(double));
     if (!acc) return -1;
     int fail = 0;
+    const float t_eps = (float)g_t_eps;
+    const float SKIPPED = 2.0f; /* alpha_acc never exceeds 1: marks a (pixel, Gaussian) visit behind the stop */
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B.nb; ++b) {
         const int y0 = b * BAND, y1 = (y0 + BAND < H) ? y0 + BAND : H;
@@ -553,6 +568,7 @@ int gso_render_backward(int N, int H, int W, const float *xy, const float *depth
                     const float power = -((ca * dx * dx + bc * dx * dy) + cd * dy * dy) * 0.5f;
                     const float w = expf(power) * op;
                     float *a = &A[(size_t)(y - y0) * W + x];
+                    if (t_eps > 0.0f && 1.0f - *a <= t_eps) { Aprev[sp++] = SKIPPED; continue; }
                     Aprev[sp++] = *a;
                     *a += w * (1.0f - *a);
                 }
@@ -579,6 +595,7 @@ int gso_render_backward(int N, int H, int W, const float *xy, const float *depth
                     const float g = expf(power);
                     const float w = g * op;
                     const float ap = Aprev[--sp];
+                    if (ap == SKIPPED) continue;
                     const float T = 1.0f - ap;
                     const float alpha = w * T;
                     const size_t p = (size_t)y * W + x;

@@ -36,6 +36,8 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.gso_scan.restype = C.c_int64
+        _lib.gso_set_t_eps.argtypes = [C.c_double]
+        _lib.gso_get_t_eps.restype = C.c_double
     return _lib
 
 
@@ -110,7 +112,13 @@ def binning(g: Geom):
                 unsorted_keys=unsorted[0], unsorted_vals=unsorted[1])
 
 
-def render_forward(g: Geom, opacities, bg):
+def _set_t_eps(t_eps):
+    """Stop threshold of the HIP path's switchable deviation (gso_set_t_eps); 0 = the reference, which never stops."""
+    lib().gso_set_t_eps(float(t_eps))
+
+
+def render_forward(g: Geom, opacities, bg, t_eps=0.0):
+    _set_t_eps(t_eps)
     op = _f32(opacities).reshape(-1)
     bg = _f32(bg)
     img = np.zeros((3, g.H, g.W), REAL)
@@ -122,7 +130,8 @@ def render_forward(g: Geom, opacities, bg):
     return img, dep, alp
 
 
-def render_backward(g: Geom, opacities, G_C, G_Z=None, G_A=None):
+def render_backward(g: Geom, opacities, G_C, G_Z=None, G_A=None, t_eps=0.0):
+    _set_t_eps(t_eps)
     op = _f32(opacities).reshape(-1)
     G_C = _f32(G_C)
     G_Z = np.zeros((1, g.H, g.W), REAL) if G_Z is None else _f32(G_Z)
@@ -160,14 +169,16 @@ def preprocess_backward(g: Geom, rb: dict):
 
 def forward_backward(H, W, sh_degree, viewmatrix, projmatrix, campos, bg, means3D, opacities, scales=None,
                      rotations=None, cov3D_precomp=None, shs=None, colors_precomp=None, G_C=None,
-                     G_Z=None, G_A=None):
-    """Whole pipeline; returns (outputs dict, grads dict or None, Geom)."""
+                     G_Z=None, G_A=None, t_eps=0.0):
+    """Whole pipeline; returns (outputs dict, grads dict or None, Geom).  t_eps > 0: the HIP path's stop threshold
+    (not in the reference; 0 restates it)."""
     g = preprocess(H, W, sh_degree, viewmatrix, projmatrix, campos, means3D, scales, rotations,
                    cov3D_precomp, shs, colors_precomp)
-    img, dep, alp = render_forward(g, opacities, bg)
+    img, dep, alp = render_forward(g, opacities, bg, t_eps)
     outs = dict(render=img, depth=dep, alpha=alp, radii=g.radii)
     grads = None
     if G_C is not None:
-        rb = render_backward(g, opacities, G_C, G_Z, G_A)
+        rb = render_backward(g, opacities, G_C, G_Z, G_A, t_eps)
         grads = preprocess_backward(g, rb)
+        grads["render_bwd"] = rb
     return outs, grads, g

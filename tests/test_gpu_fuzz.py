@@ -29,6 +29,11 @@ pytestmark = pytest.mark.gpu
 
 GRAD_REL = 1e-3
 WIDER = {}
+# the same 200 scenes at the library's default stop threshold, against the oracle applying the SAME threshold
+# (oracle/gs_oracle.c gso_set_t_eps): the default mode is held to the same bars as the exact mode, as an implementation of
+# the truncated compositing it documents.  What that truncation is worth against the reference's never-stopping
+# compositing is a stated absolute bound, enforced on the same 200 scenes by tests/test_stop_threshold_bound.py (CPU).
+NEAR_THRESHOLD = {}
 
 
 def test_fuzz_200_adversarial_scenes_vs_oracle(oracle, oracle64):
@@ -42,6 +47,34 @@ def test_fuzz_200_adversarial_scenes_vs_oracle(oracle, oracle64):
         arb = []
         try:
             F.run_case(case, dgr, oracle, t_eps=0.0, grad_rel=WIDER.get(seed, GRAD_REL), oracle64=oracle64, arbitrated=arb)
+        except AssertionError as e:
+            failures.append(f"seed {seed} (N={case['N']} {case['W']}x{case['H']} K={case['K']} deg={case['deg']}): {e}")
+        if arb:
+            arbitrated[seed] = arb
+    print(f"decided by the float64 arbiter: {arbitrated}")
+    assert not failures, "\n".join(failures)
+    assert len(arbitrated) <= 4, f"the arbiter is for the odd ill-conditioned scene, not for {len(arbitrated)} of 200"
+
+
+def test_fuzz_200_adversarial_scenes_default_stop_threshold(oracle, oracle64):
+    """t_eps_guarantee: HIP at the default t_eps == oracle at the same t_eps, image 1e-4 / depth 1e-3 / every gradient
+    tensor 1e-3 * max|grad|; a pixel whose transmittance sits within rounding of the threshold may stop one Gaussian
+    earlier or later than the oracle's (exp2-based weights vs expf), which moves a gradient by at most what
+    test_stop_threshold_bound.py bounds -- seeds where that alone exceeds the bar are listed in NEAR_THRESHOLD with the
+    bar they are held to instead."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import diff_gaussian_rasterization as dgr
+    import fuzz_parity as F
+    R = __import__("importlib").import_module("gaussian-splatting_amd.rasterizer")
+    t_eps = R.DEFAULT_T_EPS if R.DEFAULT_T_EPS > 0 else 1e-5
+    failures, arbitrated = [], {}
+    for seed in range(200):
+        case = F.make_case(seed)
+        arb = []
+        try:
+            F.run_case(case, dgr, oracle, t_eps=t_eps, grad_rel=NEAR_THRESHOLD.get(seed, GRAD_REL), oracle64=oracle64,
+                       arbitrated=arb)
         except AssertionError as e:
             failures.append(f"seed {seed} (N={case['N']} {case['W']}x{case['H']} K={case['K']} deg={case['deg']}): {e}")
         if arb:

@@ -379,6 +379,33 @@ def test_identify_tile_ranges_sparse_and_ragged(n, num_tiles, distinct, use_coun
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,n_bad,num_tiles", [(5, 1, 9), (0, 3, 9), (2049, 7, 4346), (100003, 2500, 4346), (17, 17, 300)])
+def test_identify_tile_ranges_with_trailing_keys_that_are_no_tile_ids(n, n_bad, num_tiles):
+    """Contract hardening: keys >= num_tiles at the end of the sorted list own no entry, the last valid tile is
+    closed where they begin and every tile behind it is cleared -- the table is still written in full (no garbage ranges)."""
+    import ctypes as C
+    lib = importlib.import_module("gaussian-splatting_amd._lib")
+    L = lib.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + n_bad)
+    good = np.sort(rng.integers(0, num_tiles - 1, size=n)).astype(np.uint32)      # the last tile stays empty
+    bad = np.sort(rng.integers(num_tiles, 2 ** 32 - 1, size=n_bad, dtype=np.uint64)).astype(np.uint32)
+    keys = np.concatenate([good, bad])
+    D = n + n_bad
+    buf = np.full(max(D, 8), 0xDEADBEEF, np.uint32)
+    buf[:D] = keys
+    kd = torch.from_numpy(buf.view(np.int32).copy()).to(dev)
+    ranges = torch.full((num_tiles, 2), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+    rc = L.gs_identify_tile_ranges(D, None, num_tiles, C.c_void_p(kd.data_ptr()), C.c_void_p(ranges.data_ptr()),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gs_last_error()
+    torch.cuda.synchronize()
+    ids = np.arange(num_tiles)
+    lo, hi = np.searchsorted(good, ids, side="left"), np.searchsorted(good, ids, side="right")
+    want = np.stack([np.where(hi > lo, lo, 0), np.where(hi > lo, hi, 0)], axis=1).astype(np.uint32)
+    assert np.array_equal(ranges.cpu().numpy().view(np.uint32), want)
+
+
 @pytest.mark.parametrize("n,band", [(1, None), (4095, None), (4097, (1, 3)), (300_001, None), (17_000_000, (2, 40))])
 def test_scan_tiles_offsets_and_total(n, band):
     """gs_scan_tiles through the C-ABI: boxes gathered into the given order, exclusive scan of their tile counts (inside a
@@ -486,27 +513,38 @@ def _full_size_case(dgr, oracle, N, K, H, W, backward, t_eps_list=(0.0,)):
     return sc, settings, inp, image
 
 
+def _both_modes():
+    """The reference's exact compositing (t_eps = 0) and the stop threshold a drop-in user gets by default (bench.py's)."""
+    R = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    assert R.DEFAULT_T_EPS > 0.0
+    return (0.0, R.DEFAULT_T_EPS)
+
+
 def test_config2_lego_scale_vs_oracle(dgr, oracle):
-    _full_size_case(dgr, oracle, 300_000, 16, 800, 800, backward=True)
+    _full_size_case(dgr, oracle, 300_000, 16, 800, 800, backward=True, t_eps_list=_both_modes())
 
 
 def test_config3_garden_scale_vs_oracle(dgr, oracle):
     """The configuration the headline metric is quoted on: 3 M Gaussians, SH3, 1297x840, fwd + bwd -- in the
     reference's exact mode and at the stop threshold bench.py runs at (the library default)."""
-    R = importlib.import_module("gaussian-splatting_amd.rasterizer")
-    assert R.DEFAULT_T_EPS > 0.0
-    _full_size_case(dgr, oracle, 3_000_000, 16, 840, 1297, backward=True, t_eps_list=(0.0, R.DEFAULT_T_EPS))
+    _full_size_case(dgr, oracle, 3_000_000, 16, 840, 1297, backward=True, t_eps_list=_both_modes())
 
 
 def test_config4_view_of_6M_vs_oracle(dgr, oracle):
-    """One camera view of the 6 M Gaussian view-sharded training configuration, fwd + bwd."""
-    _full_size_case(dgr, oracle, 6_000_000, 16, 840, 1297, backward=True)
+    """One camera view of the 6 M Gaussian view-sharded training configuration, fwd + bwd, both modes."""
+    _full_size_case(dgr, oracle, 6_000_000, 16, 840, 1297, backward=True, t_eps_list=_both_modes())
 
 
 def test_config5_4k_forward_vs_oracle_and_bands(dgr, oracle):
-    """10 M Gaussians at 3840x2160, forward only; the 8 tile-row bands of the sharded render equal the frame."""
+    """10 M Gaussians at 3840x2160, forward only, both modes; the 8 tile-row bands of the sharded render equal the frame
+    (compared in the exact mode: the last image _full_size_case returns is the default mode's, so it is re-rendered)."""
     par = importlib.import_module("gaussian-splatting_amd.parallel")
-    sc, settings, inp, image = _full_size_case(dgr, oracle, 10_000_000, 16, 2160, 3840, backward=False)
+    sc, settings, inp, _ = _full_size_case(dgr, oracle, 10_000_000, 16, 2160, 3840, backward=False,
+                                           t_eps_list=tuple(reversed(_both_modes())))
+    with torch.no_grad():
+        image = dgr.GaussianRasterizer(settings, t_eps=0.0)(
+            means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"], scales=inp["scales"],
+            rotations=inp["rotations"])[0]
     kw = dict(means3D=inp["means3D"], means2D=None, shs=inp["shs"], opacities=inp["opacities"],
               scales=inp["scales"], rotations=inp["rotations"], t_eps=0.0)
     with torch.no_grad():

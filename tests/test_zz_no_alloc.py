@@ -43,7 +43,11 @@ def test_static_sort_equals_workspace_sort_two_calls_in_a_row():
     # (pairs, capacity slack, key bits, count on the device): large first, then smaller ones
     cases = [(1_500_003, 0, 32, False), (70_001, 5000, 13, True), (4097, 0, 32, False), (1, 0, 8, False)]
     with torch.cuda.device(dev):
-        torch.zeros(1, device=dev)                       # context + first-call set-up outside the memory check
+        torch.zeros(1, device=dev)                       # context
+        # the documented set-up call (include/gsplat.h): D = 0, first call on the device -- when this file runs alone it is
+        # the library's first HIP call altogether (code object load, symbol address); every later call must allocate nothing
+        in_b = C.c_int(-1)
+        assert L.gs_sort_pairs_static(0, None, 0, 32, None, None, None, None, C.byref(in_b), None) == 0 and in_b.value == 0
         for n, slack, bits, use_count in cases:
             rng = np.random.default_rng(n)
             cap = n + slack

@@ -7,7 +7,7 @@ far off screen, screen-filling, needle-thin, almost transparent, almost opaque, 
 compares image / depth / alpha / radii / every gradient with the tolerances of tests/util.py.  Test infrastructure
 (it drives the oracle); the seeds that matter are frozen in tests/test_gpu_fuzz.py.
 
-usage: python tools/fuzz_parity.py [first_seed] [cases] [t_eps]
+usage: python tools/fuzz_parity.py [first_seed] [cases] [t_eps] [oracle_t_eps (default: t_eps)]
 """
 import importlib
 import math
@@ -89,15 +89,17 @@ INPUTS = ("means3D", "opacities", "scales", "rotations", "cov3D_precomp", "shs",
 ARBITER_NOISE_FRAC = 0.25
 
 
-def _oracle_call(orc, case):
+def _oracle_call(orc, case, t_eps=0.0):
+    """t_eps > 0: the oracle applies the HIP path's stop rule too (oracle/gs_oracle.c gso_set_t_eps), so the default mode
+    is held to the same bar as the exact mode -- as an implementation of the truncated compositing it documents."""
     return orc.forward_backward(
         case["H"], case["W"], case["deg"], case["viewmatrix"], case["projmatrix"], case["campos"], case["bg"],
         case["means3D"], case["opacities"], scales=case["scales"], rotations=case["rotations"],
         cov3D_precomp=case["cov3D_precomp"], shs=case["shs"], colors_precomp=case["colors_precomp"], G_C=case["G_C"],
-        G_Z=case["G_Z"], G_A=case["G_A"])
+        G_Z=case["G_Z"], G_A=case["G_A"], t_eps=t_eps)
 
 
-def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None, oracle64=None, arbitrated=None):
+def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None, oracle64=None, arbitrated=None, oracle_t_eps=None):
     """Raises AssertionError on a mismatch; returns the worst relative gradient error.
 
     The bar for every gradient tensor is grad_rel * max|grad| against the fp32 oracle.  oracle64 (optional: the float64
@@ -105,11 +107,14 @@ def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None, oracle64=None, arbitra
     evaluation exceeds ARBITER_NOISE_FRAC of the bar (the scene is ill-conditioned in fp32: the reference arithmetic
     itself does not pin the value to the bar) and both evaluations took the same discrete decisions (boxes, radii),
     the HIP result must be within the SAME bar of the float64 evaluation instead.  `arbitrated` (a list) collects the
-    names of tensors decided that way."""
+    names of tensors decided that way.  oracle_t_eps: the stop threshold the ORACLE runs at (default: the same t_eps as
+    the HIP path; 0 compares a truncating HIP run with the reference's never-stopping compositing)."""
+    if oracle_t_eps is None:
+        oracle_t_eps = t_eps
     from util import TOL_DEPTH, TOL_GRAD_REL, TOL_IMAGE, check_grad
     dev = torch.device("cuda:0")
     H, W = case["H"], case["W"]
-    outs, grads, geom = _oracle_call(oracle, case)
+    outs, grads, geom = _oracle_call(oracle, case, oracle_t_eps)
     t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
     inp = {k: (None if case[k] is None else t(case[k]).requires_grad_(True)) for k in INPUTS}
     settings = dgr.GaussianRasterizationSettings(
@@ -144,7 +149,7 @@ def run_case(case, dgr, oracle, t_eps=0.0, grad_rel=None, oracle64=None, arbitra
                 if oracle64 is None:
                     raise
                 if exact is None:
-                    _, g64, geom64 = _oracle_call(oracle64, case)
+                    _, g64, geom64 = _oracle_call(oracle64, case, oracle_t_eps)
                     same = np.array_equal(geom64.rect, geom.rect) and np.array_equal(geom64.radii, geom.radii)
                     exact = (g64, same)
                 g64, same = exact
@@ -163,6 +168,7 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     t_eps = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+    oracle_t_eps = float(sys.argv[4]) if len(sys.argv) > 4 else None
     import diff_gaussian_rasterization as dgr
     from oracle import oracle, oracle64
     oracle.build()
@@ -174,7 +180,7 @@ def main():
                f"{'cov' if case['cov3D_precomp'] is not None else 'sr'}/{'rgb' if case['colors_precomp'] is not None else 'sh'}")
         try:
             arb = []
-            worst = run_case(case, dgr, oracle, t_eps, oracle64=oracle64, arbitrated=arb)
+            worst = run_case(case, dgr, oracle, t_eps, oracle64=oracle64, arbitrated=arb, oracle_t_eps=oracle_t_eps)
             print(f"ok   {tag} worst grad err {worst:.2e}" + (f" (float64 arbiter: {', '.join(arb)})" if arb else ""), flush=True)
         except AssertionError as e:
             bad += 1

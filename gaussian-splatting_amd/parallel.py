@@ -401,96 +401,132 @@ def bucket_ranges(n: int, num_buckets: int, align: int = 256):
     return [(b, min(b + per, n)) for b in range(0, n, per)]
 
 
-class _RasterizeReplicated(torch.autograd.Function):
-    """rasterizer.rasterize_gaussians whose backward runs gs_preprocess_bwd per Gaussian range and all-reduces each
-    range's gradients as soon as its launch is queued (see ViewShardedRasterizer)."""
+class _RasterizeViews(torch.autograd.Function):
+    """k camera views of the same (replicated) Gaussians as ONE autograd node: the forward renders every view; the
+    backward adds the views' gradients up in place -- gs_preprocess_bwd's `accumulate` flag, no per-view gradient
+    tensors -- and, for the LAST view, runs gs_preprocess_bwd per Gaussian range and all-reduces each range's
+    gradients as soon as its launch is queued (see ViewShardedStep).  Outputs: k images, k radii, k depths, k alphas."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                settings, t_eps, need_grad, owner):
+                views, t_eps, need_grad, owner):
         from . import rasterizer as R
         dev = means3D.device
+        per_view = []
         with torch.cuda.device(dev):
-            band = R._band(settings, None)
-            state = R.preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                         colors_precomp, None, want_jac=need_grad)
-            image, depth, alpha, aux, rows = R.render_forward(settings, state.splat, state.ranges, state.point_list,
-                                                              need_grad, t_eps, band)
-        ctx.rows, ctx.settings, ctx.t_eps, ctx.band, ctx.owner = rows, settings, float(t_eps), band, owner
+            for settings in views:
+                band = R._band(settings, None)
+                state = R.preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                             colors_precomp, None, want_jac=need_grad)
+                image, depth, alpha, aux, rows = R.render_forward(settings, state.splat, state.ranges, state.point_list,
+                                                                  need_grad, t_eps, band)
+                per_view.append((state, image, depth, alpha, aux, rows, band))
+        k = len(views)
+        ctx.k, ctx.views, ctx.t_eps, ctx.owner = k, list(views), float(t_eps), owner
+        ctx.bands = [pv[6] for pv in per_view]
+        ctx.rows = [pv[5] for pv in per_view]
         ctx.set_materialize_grads(False)
         ctx.has = tuple(t is not None for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
-        saved = [means3D, opacities, state.splat, state.radii, state.point_list, state.ranges, depth, alpha]
+        saved = [means3D, opacities]
         saved += [t for t in (shs, colors_precomp, scales, rotations, cov3D_precomp) if t is not None]
-        ctx.has_aux = aux is not None
-        if aux is not None:
-            saved.append(aux)
-        ctx.has_jac = state.sh_jac is not None
-        if ctx.has_jac:
-            saved.append(state.sh_jac)
+        ctx.has_aux = need_grad
+        ctx.has_jac = per_view[0][0].sh_jac is not None if k else False
+        for state, image, depth, alpha, aux, rows, band in per_view:
+            saved += [state.splat, state.radii, state.point_list, state.ranges, depth, alpha]
+            if ctx.has_aux:
+                saved.append(aux)
+            if ctx.has_jac:
+                saved.append(state.sh_jac)
         ctx.save_for_backward(*saved)
-        ctx.mark_non_differentiable(state.radii)
-        return image, state.radii, depth, alpha
+        radii = [pv[0].radii for pv in per_view]
+        ctx.mark_non_differentiable(*radii)
+        return (*[pv[1] for pv in per_view], *radii, *[pv[2] for pv in per_view], *[pv[3] for pv in per_view])
 
     @staticmethod
-    def backward(ctx, g_image, g_radii, g_depth, g_alpha):
+    def backward(ctx, *g_out):
         from . import rasterizer as R
+        k, owner = ctx.k, ctx.owner
+        g_images, g_depths, g_alphas = g_out[:k], g_out[2 * k:3 * k], g_out[3 * k:4 * k]
         saved = list(ctx.saved_tensors)
-        means3D, opacities, splat, radii, point_list, ranges, depth, alpha = saved[:8]
-        rest = saved[8:]
+        means3D, opacities = saved[:2]
+        rest = saved[2:]
         shs, colors_precomp, scales, rotations, cov3D_precomp = [rest.pop(0) if h else None for h in ctx.has]
         if not ctx.has_aux:
             raise RuntimeError("backward called but no input required grad in forward")
-        aux = rest.pop(0)
-        sh_jac = rest.pop(0) if ctx.has_jac else None
-        owner, settings = ctx.owner, ctx.settings
+        per_view = []
+        for _ in range(k):
+            splat, radii, point_list, ranges, depth, alpha = rest[:6]
+            del rest[:6]
+            aux = rest.pop(0)
+            jac = rest.pop(0) if ctx.has_jac else None
+            per_view.append((splat, radii, point_list, ranges, depth, alpha, aux, jac))
         dev = means3D.device
         N = means3D.shape[0]
         needs = list(ctx.needs_input_grad[:8])
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rows, ctx.rows = ctx.rows, None
-            rows = R.render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_image, g_depth, g_alpha,
-                                     rows, ctx.t_eps, ctx.band)
             # full-size destinations, in the order of GaussianRasterizer.forward's arguments; means2D's gradient is a
-            # per-view statistic (densification) and is NOT summed over ranks
+            # per-view statistic (densification): one (N, 3) slab per view, NOT summed over views or ranks
             per_row = (means3D, None, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
             full = [torch.empty_like(t) if (t is not None and needs[i]) else None for i, t in enumerate(per_row)]
+            m2d_rows = False
             if needs[1] and ctx.means2D_shape is not None:
-                full[1] = torch.empty((N, 3), **f32) if ctx.means2D_shape == (N, 3) else torch.zeros(ctx.means2D_shape, **f32)
-            m2d_rows = full[1] is not None and ctx.means2D_shape == (N, 3)
+                m2d_rows = ctx.means2D_shape in ((k, N, 3), (N, 3)) and (k == 1 or ctx.means2D_shape == (k, N, 3))
+                full[1] = torch.empty(ctx.means2D_shape, **f32) if m2d_rows else torch.zeros(ctx.means2D_shape, **f32)
+            m2d_views = full[1].view(k, N, 3) if m2d_rows else None
             reduce_now = owner.world > 1 or owner.force_collectives
             works = []
-            # lean per-range launches: the camera tensors are converted once and the C-ABI is called on base pointers
-            # + row offsets (the host must queue 2 kernels and one grouped all-reduce per range faster than the GPU
-            # finishes them, or the overlap is lost to launch gaps)
+            # lean launches: the camera tensors are converted once per view and the C-ABI is called on base pointers + row
+            # offsets (per range the host must queue 2 kernels and one grouped all-reduce faster than the GPU finishes
+            # them, or the overlap is lost to launch gaps)
             lib = R._lib.load()
             K = shs.shape[1] if shs is not None else 0
-            cam = [R._camera_tensor(getattr(settings, k), n, k, dev) for k, n in
-                   (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
-            cam_p = [R._ptr(t) for t in cam]
             st = R._stream()
-            H, W = settings.image_height, settings.image_width
 
             def at(t, b):
                 return None if t is None else R.C.c_void_p(t.data_ptr() + b * t.stride(0) * 4)
 
-            g_m3, g_m2, g_sh, g_col, g_op, g_sc, g_rot, g_cov = full
-            if not m2d_rows:
-                g_m2 = None
-            jac = sh_jac if shs is not None else None     # (N, 12): a range is a row slice like everything else
-            for (b, e) in bucket_ranges(N, owner.num_buckets):
-                with _stage("preprocess_bwd"):
-                    R._lib.check(lib.gs_preprocess_bwd(
-                        e - b, K, settings.sh_degree, H, W, *cam_p, at(means3D, b), at(scales, b), at(rotations, b),
-                        at(cov3D_precomp, b), at(opacities, b), at(shs, b), at(colors_precomp, b), at(radii, b), at(rows, b),
-                        at(g_m3, b), at(g_m2, b), at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b), at(g_sh, b),
-                        at(g_col, b), 0, at(jac, b), st),
-                        "gs_preprocess_bwd")
-                if reduce_now:      # queued behind this range's launches on RCCL's stream; the next range's kernels overlap it
-                    with _stage("allreduce_launch"):
-                        works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
-                                                     owner.group, async_op=True))
+            g_m3, _, g_sh, g_col, g_op, g_sc, g_rot, g_cov = full
+            live = [v for v in range(k) if not (g_images[v] is None and g_depths[v] is None and g_alphas[v] is None)]
+            if not live:                       # no view's outputs were used: zero gradients (still all-reduced below)
+                for i, t in enumerate(full):
+                    if t is not None:
+                        t.zero_()
+            elif m2d_views is not None and len(live) < k:
+                m2d_views.zero_()
+            written = False
+            for v in live:
+                settings = ctx.views[v]
+                splat, radii, point_list, ranges, depth, alpha, aux, jac = per_view[v]
+                rows, ctx.rows[v] = ctx.rows[v], None          # cleared by the forward; a second backward clears its own
+                rows = R.render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_images[v], g_depths[v],
+                                         g_alphas[v], rows, ctx.t_eps, ctx.bands[v])
+                cam_p = [R._ptr(R._camera_tensor(getattr(settings, name), n, name, dev)) for name, n in
+                         (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
+                H, W = settings.image_height, settings.image_width
+                g_m2 = m2d_views[v] if m2d_views is not None else None
+                jac = jac if shs is not None else None     # (N, 12): a range is a row slice like everything else
+                last = v == live[-1]
+                # every view but the last: one launch over all N; the last: per range, each followed by its all-reduce
+                spans = bucket_ranges(N, owner.num_buckets) if (last and reduce_now) else ([(0, N)] if N else [])
+                for (b, e) in spans:
+                    with _stage("preprocess_bwd"):
+                        R._lib.check(lib.gs_preprocess_bwd(
+                            e - b, K, settings.sh_degree, H, W, *cam_p, at(means3D, b), at(scales, b), at(rotations, b),
+                            at(cov3D_precomp, b), at(opacities, b), at(shs, b), at(colors_precomp, b), at(radii, b),
+                            at(rows, b), at(g_m3, b), at(g_m2, b), at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b),
+                            at(g_sh, b), at(g_col, b), 1 if written else 0, at(jac, b), st),
+                            "gs_preprocess_bwd")
+                    if last and reduce_now:   # queued behind this range's launches on RCCL's stream; the next range's kernels overlap it
+                        with _stage("allreduce_launch"):
+                            works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
+                                                         owner.group, async_op=True))
+                written = True
+            if not live and reduce_now:       # keep the collective sequence identical on every rank
+                for (b, e) in bucket_ranges(N, owner.num_buckets):
+                    works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
+                                                 owner.group, async_op=True))
             with _stage("allreduce_wait"):
                 for w in works:
                     _wait(w)
@@ -501,27 +537,35 @@ class _RasterizeReplicated(torch.autograd.Function):
         return (*full, None, None, None, None)
 
 
-class ViewShardedRasterizer:
-    """The training pattern BASELINE.json's north_star names: every rank holds ALL Gaussians
-    and renders its own camera view; the one exchange step is the SUM of the per-Gaussian gradients (59 floats per
-    Gaussian at SH degree 3), bucketed along the Gaussian axis and overlapped with the backward.  No counterpart in
-    the reference (one view per iteration on one device, train.py:129-135); equal to sequential accumulation of the
-    same views on one device up to fp32 summation order.
+class ViewShardedStep:
+    """One training step of the pattern BASELINE.json's north_star names (6 M Gaussians, 8 camera
+    views per step): every rank holds ALL Gaussians and renders ITS views of the step -- shard_views(num_views, rank,
+    world), i.e. 8 / world of them -- and the one exchange of the step is the SUM of the per-Gaussian gradients (59 floats
+    per Gaussian at SH degree 3).  No counterpart in the reference (one view per iteration on one device,
+    train.py:129-135); equal to sequential accumulation of the same views on one device up to fp32 summation order.
 
-    The backward runs gs_preprocess_bwd once per bucket -- the C-ABI takes base pointers and a count, so a bucket
-    is a row slice of every per-Gaussian tensor -- and launches that bucket's all-reduce (one grouped RCCL call
-    over its slices of the gradient tensors) right after its kernels are queued: RCCL's stream starts on bucket b
-    while this stream computes bucket b + 1, and only the last bucket's transfer is exposed.  The gradients that
-    autograd hands to the parameters are already summed over the ranks (divided by the world size if `average`).
-    means2D's gradient (the densification statistic, per view) and radii are not exchanged: reduce them with
-    reduce_densify_stats after folding them into the per-Gaussian statistics.
+    The backward adds the local views up in place (gs_preprocess_bwd's `accumulate` flag: views 1..k-1 of the rank cost
+    no gradient tensors of their own and no collective); the LAST local view runs gs_preprocess_bwd once per Gaussian
+    range -- the C-ABI takes base pointers and a count, so a range is a row slice of every per-Gaussian tensor -- and
+    launches that range's all-reduce (one grouped RCCL call over its slices of the gradient tensors) right after its
+    kernels are queued: RCCL's stream starts on range b while this stream computes range b + 1, and only the last
+    range's transfer is exposed.  One exchange per step, whatever the number of local views: the wire time is amortised
+    over 8 / world views.  The gradients autograd hands to the parameters are already summed over views and ranks
+    (divided by the world size if `average`).  means2D (optional, (k, N, 3)): its gradient is the per-view screen-space
+    gradient (the densification statistic); it and radii (k of them) are not exchanged -- fold them into the per-Gaussian
+    statistics view by view, then call reduce_densify_stats ONCE per step.
 
-    Usable as a drop-in for GaussianRasterizer(raster_settings): same call signature, same 4-tuple."""
+        step = ViewShardedStep([settings of my views], num_buckets=4)
+        images, radii, depths, alphas = step(means3D=..., means2D=zeros(k, N, 3), shs=..., ...)   # lists of k
+        sum(loss(images[j], gt[j]) for j in range(k)).backward()
+    """
 
-    def __init__(self, raster_settings, t_eps=None, num_buckets: int = 4, average: bool = False,
+    def __init__(self, views, t_eps=None, num_buckets: int = 4, average: bool = False,
                  group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False):
         from .rasterizer import DEFAULT_T_EPS
-        self.raster_settings = raster_settings
+        self.views = list(views)
+        if not self.views:
+            raise ValueError("ViewShardedStep needs at least one view per rank (give every rank a view, or a smaller world)")
         self.t_eps = DEFAULT_T_EPS if t_eps is None else t_eps
         self.num_buckets = int(num_buckets)
         self.average = average
@@ -533,8 +577,28 @@ class ViewShardedRasterizer:
     def __call__(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
                  rotations=None, cov3D_precomp=None, cov3Ds_precomp=None):
         from . import rasterizer as R
-        m3, m2, sh, col, op, sc, rot, cov = R.check_inputs(self.raster_settings, means3D, means2D, shs, colors_precomp,
-                                                           opacities, scales, rotations, cov3D_precomp, cov3Ds_precomp)
-        need_grad = R.wants_grad(m3, m2, sh, col, op, sc, rot, cov)
-        return _RasterizeReplicated.apply(m3, m2, sh, col, op, sc, rot, cov, self.raster_settings, self.t_eps,
-                                          need_grad, self)
+        k = len(self.views)
+        m3 = sh = col = op = sc = rot = cov = None
+        for rs in self.views:     # the argument checks of GaussianRasterizer.forward, against every view's settings
+            m3, _, sh, col, op, sc, rot, cov = R.check_inputs(rs, means3D, None, shs, colors_precomp, opacities, scales,
+                                                               rotations, cov3D_precomp, cov3Ds_precomp)
+        N = m3.shape[0]
+        if means2D is not None and tuple(means2D.shape) != (k, N, 3) and not (k == 1 and tuple(means2D.shape) == (N, 3)):
+            raise ValueError(f"means2D must be ({k}, {N}, 3): one screen-space gradient per local view")
+        need_grad = R.wants_grad(m3, means2D, sh, col, op, sc, rot, cov)
+        out = _RasterizeViews.apply(m3, means2D, sh, col, op, sc, rot, cov, self.views, self.t_eps, need_grad, self)
+        return list(out[:k]), list(out[k:2 * k]), list(out[2 * k:3 * k]), list(out[3 * k:4 * k])
+
+
+class ViewShardedRasterizer(ViewShardedStep):
+    """ViewShardedStep with ONE view per rank and step, as a drop-in for GaussianRasterizer(raster_settings): same call
+    signature, same 4-tuple; the backward's per-range gs_preprocess_bwd launches overlap the bucketed all-reduce."""
+
+    def __init__(self, raster_settings, t_eps=None, num_buckets: int = 4, average: bool = False,
+                 group: Optional[dist.ProcessGroup] = None, force_collectives: bool = False):
+        super().__init__([raster_settings], t_eps, num_buckets, average, group, force_collectives)
+        self.raster_settings = raster_settings
+
+    def __call__(self, *args, **kwargs):
+        images, radii, depths, alphas = super().__call__(*args, **kwargs)
+        return images[0], radii[0], depths[0], alphas[0]

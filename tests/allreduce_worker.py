@@ -107,7 +107,48 @@ def main():
     assert torch.allclose(accum, want_acc, rtol=1e-6, atol=0)
     assert torch.equal(denom, sum((ref_radii[v] > 0).float()[:, None] for v in range(world)))
     assert torch.equal(maxr, torch.stack([r.float() for r in ref_radii]).max(dim=0).values)
+    # ---- (3) BASELINE.json config 4's pattern: several views per rank and step, ONE exchange per step.  2 * world views,
+    # rank r renders views r and r + world (parallel.shard_views); local views add up in place, the last one's backward
+    # carries the bucketed all-reduce.  Reference: one process accumulating all 2 * world views in view order.
+    nv = 2 * world
+    views2 = [syn.jitter_view(base, 10 + v) for v in range(nv)]
+    sets2 = [settings(v) for v in views2]
+    Gs2 = [(torch.rand(3, H, W, generator=gen) * 2 - 1).to(dev) for _ in range(nv)]
+    ref2 = leaves()
+    ref2_m2d, ref2_img = {}, {}
+    for v in range(nv):
+        mv = torch.zeros((N, 3), device=dev, requires_grad=True)
+        out = impl.GaussianRasterizer(sets2[v])(means2D=mv, **ref2)
+        (out[0] * Gs2[v]).sum().backward()
+        ref2_m2d[v], ref2_img[v] = mv.grad, out[0].detach()
+    my_views = par.shard_views(nv, rank, world)
+    assert len(my_views) == 2
+    mine3 = leaves()
+    m2d3 = torch.zeros((len(my_views), N, 3), device=dev, requires_grad=True)
+    step = par.ViewShardedStep([sets2[v] for v in my_views], num_buckets=3)
+    images, radii3, _, _ = step(means2D=m2d3, **mine3)
+    for j, v in enumerate(my_views):
+        assert torch.equal(images[j], ref2_img[v]), "multi-view step: image differs from the single-GPU render"
+    sum((images[j] * Gs2[v]).sum() for j, v in enumerate(my_views)).backward()
+    w3 = {}
+    for k in data:
+        want = ref2[k].grad
+        w3[k] = (mine3[k].grad - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert w3[k] <= TOL_GRAD_REL, ("multi-view step", k, w3[k])
+    for j, v in enumerate(my_views):
+        assert torch.equal(m2d3.grad[j], ref2_m2d[v]), "multi-view step: means2D's gradient must stay per view"
+    # only the first view's output used: the other view contributes nothing, the collective sequence is unchanged
+    mine4 = leaves()
+    images, _, _, _ = par.ViewShardedStep([sets2[v] for v in my_views], num_buckets=3)(**mine4)
+    (images[0] * Gs2[my_views[0]]).sum().backward()
+    ref4 = leaves()
+    for v in range(world):        # the first local view of every rank: views 0 .. world - 1
+        (impl.GaussianRasterizer(sets2[v])(**ref4)[0] * Gs2[v]).sum().backward()
+    for k in data:
+        e = (mine4[k].grad - ref4[k].grad).abs().max().item() / max(ref4[k].grad.abs().max().item(), 1e-30)
+        assert e <= TOL_GRAD_REL, ("multi-view step, one output unused", k, e)
     torch.cuda.synchronize()
+    print(f"rank {rank}: multi-view step", {k: f"{v:.1e}" for k, v in w3.items()}, flush=True)
     print(f"rank {rank}: OK overlapped", {k: f"{v:.1e}" for k, v in w1.items()}, "reducer",
           {k: f"{v:.1e}" for k, v in w2.items()}, flush=True)
     dist.barrier()

@@ -535,6 +535,53 @@ def test_config4_view_of_6M_vs_oracle(dgr, oracle):
     _full_size_case(dgr, oracle, 6_000_000, 16, 840, 1297, backward=True, t_eps_list=_both_modes())
 
 
+def test_config4_eight_view_step_at_6M_vs_oracle_sum(dgr, oracle):
+    """BASELINE.json config 4 as written, on one GPU: ONE training step = 8 camera views of the same 6 M Gaussians
+    (parallel.ViewShardedStep, the 1-GPU leg of the view-sharded step: views accumulated in place, no collective), against
+    the oracle's gradients summed over the same 8 views (8 oracle frames: the slow part).  Every image bit-identical to the
+    plain rasterizer's; every gradient tensor within the stated 1e-3 * max|grad| of the oracle's sum; means2D's gradient
+    stays per view."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+    N, K, H, W, V = 6_000_000, 16, 840, 1297, 8
+    sc = syn.make_scene(N, K, H, W, seed=0)
+    dev = torch.device("cuda:0")
+    oracle.set_threads(min(oracle.max_threads(), 16))
+    a = lambda t: t.numpy()  # noqa: E731
+    views = [syn.jitter_view(sc, v) for v in range(V)]
+    gen = torch.Generator().manual_seed(4)
+    Gs = [torch.rand(3, H, W, generator=gen) * 2 - 1 for _ in range(V)]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    ref = None
+    for v, G in zip(views, Gs):
+        _, g, _ = oracle.forward_backward(H, W, sc.sh_degree, a(v.viewmatrix), a(v.projmatrix), a(v.campos), a(sc.bg),
+                                          a(sc.means3D), a(sc.opacities), scales=a(sc.scales), rotations=a(sc.rotations),
+                                          shs=a(sc.shs), G_C=a(G))
+        if ref is None:
+            ref = {k: g[k].astype(np.float64) for k in names}
+        else:
+            for k in names:
+                ref[k] += g[k]
+        del g
+    inp = {k: v.clone().requires_grad_(True) for k, v in _scene_inputs(sc, dev).items()}
+    sets = [_scene_settings(dgr, v, dev) for v in views]
+    step = par.ViewShardedStep(sets, t_eps=0.0)
+    m2d = torch.zeros((V, N, 3), device=dev, requires_grad=True)
+    images, radii, depths, alphas = step(means3D=inp["means3D"], means2D=m2d, shs=inp["shs"], opacities=inp["opacities"],
+                                         scales=inp["scales"], rotations=inp["rotations"])
+    sum((img * G.to(dev)).sum() for img, G in zip(images, Gs)).backward()
+    torch.cuda.synchronize()
+    for k in names:
+        check_grad("config4 step:d_" + k, inp[k].grad.cpu().numpy(), ref[k])
+    # one view through the plain rasterizer: same image bit for bit, same per-view screen-space gradient
+    with torch.no_grad():
+        img3 = dgr.GaussianRasterizer(sets[3], t_eps=0.0)(means3D=inp["means3D"], means2D=None, shs=inp["shs"],
+                                                           opacities=inp["opacities"], scales=inp["scales"],
+                                                           rotations=inp["rotations"])[0]
+    assert torch.equal(img3, images[3].detach())
+    assert m2d.grad.shape == (V, N, 3) and float(m2d.grad[5].abs().max()) > 0 and not torch.equal(m2d.grad[5], m2d.grad[6])
+
+
 def test_config5_4k_forward_vs_oracle_and_bands(dgr, oracle):
     """10 M Gaussians at 3840x2160, forward only, both modes; the 8 tile-row bands of the sharded render equal the frame
     (compared in the exact mode: the last image _full_size_case returns is the default mode's, so it is re-rendered)."""

@@ -626,8 +626,16 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
         if (POOL > 0) {
             const uint32_t dead = dead_row_mask(P);
             for (bool first = true;; first = false) {
+#ifdef GS_STATS
+                __shared__ int stat_cnt[NBLK];
+                int cq[GS_ROWS];
+                nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave], dead,
+                                             cq, first);
+                if (lane < GS_ROWS) stat_cnt[wave * GS_ROWS + lane] = cq[lane];
+#else
                 nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave], dead,
                                              nullptr, first);
+#endif
                 // every row of a wave gets the wave's longest list: a wave walks nmax positions with all four rows, and a
                 // row whose own list is shorter still stores (zeros) at the positions behind it
                 if (lane < GS_ROWS) row_cnt[wave * GS_ROWS + lane] = (uint32_t)nmax;
@@ -641,6 +649,22 @@ __global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
                 if (total <= (uint32_t)POOL || n == 1) {
+#ifdef GS_STATS
+                    if (tid == 0) {       // what a sorted block -> wave assignment would walk
+                        int cs[NBLK], live = 0, geo = 0, srt = 0, srt8 = 0;
+                        for (int i = 0; i < NBLK; ++i) { cs[i] = stat_cnt[i]; live += cs[i]; }
+                        for (int w = 0; w < NW; ++w) geo += 4 * max(max(cs[4 * w], cs[4 * w + 1]), max(cs[4 * w + 2], cs[4 * w + 3]));
+                        for (int i = 1; i < NBLK; ++i) { const int v = cs[i]; int j = i; while (j > 0 && cs[j - 1] < v) { cs[j] = cs[j - 1]; --j; } cs[j] = v; }
+                        for (int w = 0; w < NW; ++w) srt += 4 * cs[4 * w];
+                        srt8 = 8 * cs[0] + 8 * cs[8];
+                        atomicAdd(&gs_dbg[11], (unsigned long long)live);
+                        atomicAdd(&gs_dbg[12], (unsigned long long)geo);
+                        atomicAdd(&gs_dbg[13], (unsigned long long)srt);
+                        atomicAdd(&gs_dbg[14], (unsigned long long)srt8);
+                        int nz = 0; for (int w = 0; w < NW; ++w) nz += cs[4 * w] > 0;
+                        atomicAdd(&gs_dbg[15], (unsigned long long)nz);
+                    }
+#endif
                     flush_base = incl - own;                                                // block tid & 15 = lane & 15
                     if (lane < NBLK) row_base[wave][lane] = flush_base;                     // own row's base: via LDS, this wave only
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -24,3 +24,7 @@ for t_eps in (1e-5, 0.0):
           f"active lanes {v[4]} ({v[4]/max(v[3],1)/64:.3f} of the lanes of executed visits), live rows {v[5]} ({v[5]/max(v[3],1)/4:.3f}), "
           f"flush rounds {v[6]} (executed {v[7]}), valid flush lanes {v[9]} ({v[9]/max(v[7],1)/64:.3f}), "
           f"batches culled again for the slot pool (x4 waves) {v[10]}")
+    if v[12]:
+        print(f"   block-list entries {v[11]}; row-visits with the geometric block -> wave assignment {v[12]} (live {v[11]/v[12]:.3f}), with blocks "
+              f"sorted by list length into groups of four {v[13]} (live {v[11]/max(v[13],1):.3f}, {v[13]/v[12]:.3f} of the visits), "
+              f"groups of eight {v[14]} (live {v[11]/max(v[14],1):.3f}); waves with any list after sorting {v[15]} of {v[0]}")

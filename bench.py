@@ -281,8 +281,11 @@ def main():
     else:
         # N > 1 over xGMI has never been run by the builder (one-GPU boxes): time a few steps of both partitionings,
         # run the timed region on the faster, report both.  A mode that raises is reported as such; if both do, exit.
-        probe = {}
+        probe, per_view, views_of = {}, {}, {}
         for m in ("allreduce", "exchange"):
+            if m == "exchange" and vps not in (None, world):
+                probe[m] = "not applicable (one view per rank and step)"
+                continue
             ok = 1
             try:
                 setup(m)
@@ -299,11 +302,16 @@ def main():
                 ok, ms = 0, float("inf")
             t = torch.tensor([float(ok), -ms if ok else -1e30], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)            # all ranks ok, and the slowest rank's time
-            probe[m] = round(-float(t[1].item()), 4) if int(t[0].item()) == 1 else "failed"
-        good = {m: v for m, v in probe.items() if v != "failed"}
-        if not good:
+            if int(t[0].item()) == 1:
+                probe[m] = round(-float(t[1].item()), 4)
+                per_view[m] = probe[m] / step_views             # the modes render different numbers of views per step
+                views_of[m] = step_views
+            else:
+                probe[m] = "failed"
+        if not per_view:
             raise SystemExit("[bench] both multi-GPU modes failed (see stderr of the ranks)")
-        setup(min(good, key=good.get))
+        probe["views_per_step"] = views_of
+        setup(min(per_view, key=per_view.get))
     exchange = mode == "exchange"
     for _ in range(args.warmup):
         step()
@@ -458,7 +466,7 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])},
         }
         if probe is not None:
-            out["parallel_probe_ms_per_step"] = probe
+            out["parallel_probe_ms_per_step"] = probe      # per STEP; the faster mode per VIEW runs the timed region
         if multi or views_per_rank > 1:   # several launches of a stage per step (one per view / bucket): mean per launch above, launches here
             out["stage_launches_per_step"] = {k: round(v, 2) for k, v in calls_per_step.items() if v != 1.0}
             if mode == "allreduce":

@@ -166,6 +166,19 @@ int gs_render_fwd(int H, int W, const float* bg, const void* splat, const uint32
  * arrive -- and four floats (bytes 48..63): d/d rgb, d/d depth.  The rows are an opaque hand-over to
  * gs_preprocess_bwd, which turns the moments into d/d screen mean, d/d conic and d/d opacity.
  * t_eps must equal the forward's.  Gaussian indices (point_list) must be below 2^30 (gs_preprocess_fwd rejects more).
+ * What it differentiates: the forward as gs_render_fwd ran it.  A pixel that stopped (1 - alpha_acc <= t_eps; at
+ * t_eps = 0: alpha_acc == 1 exactly) composites nothing behind the stop, and the part of a pixel's sum behind the
+ * Gaussian that stops it is taken as 0 -- the exact gradient of the truncated forward (bounds against the reference's
+ * never-stopping compositing: tests/test_stop_threshold_bound.py).
+ * Documented deviation from the reference's autograd, the w == 1 corner: a Gaussian whose weight at a pixel is exactly
+ * 1.0 (opacity 1.0 AND the screen mean on the pixel centre; the reference's sigmoid opacities cannot reach it) drives the
+ * transmittance to exactly 0.  Autograd gives dL/dw_i = T_i (u_i - S_i) there, S_i = what the Gaussians behind it would
+ * show through it (a one-sided derivative that needs the hidden part of the list); this backward replays front to back
+ * and returns T_i u_i.  Only dL/d opacity_i is affected (d power / d mean and d conic vanish at dx = dy = 0).  Pinned by
+ * tests/test_w_equals_one.py: the CPU oracle equals autograd, the HIP path equals oracle + T_i S_i.
+ * Conditioning: for a pixel that does not stop, the part behind Gaussian i enters as (total - prefix) / (1 - w_i); with
+ * 1 - w_i below ~1e-6 (opacity within 1e-6 of 1 and the pixel within ~1e-3 px of the mean) at t_eps = 0 the fp32 residue
+ * of that difference is amplified beyond the stated tolerance -- at any t_eps >= 1e-6 such a visit stops the pixel.
  */
 int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const uint32_t* point_list,
                   const float* aux_rgb, const float* out_depth, const float* out_alpha,

@@ -122,3 +122,30 @@ def test_pair_capacity_cache_is_per_device_and_tile_grid_and_thread_safe():
     [t.join() for t in ts]
     assert all(c.get((0, k, k, 0, k)) == 1999 + 1999 // 4 + 4096 for k in range(1, 9))
     assert isinstance(rz._pair_capacity, rz.PairCapacityCache)
+
+
+def test_byte_model_of_the_factored_sort():
+    """bench.py prices each sort launch on the bytes it moves: the v1 row charges 6 passes of 24 B over
+    the D pairs, the build runs 4 passes over the N depth keys + 2 over the D tile ids."""
+    import bench
+    N, D = 3_000_000, 7_535_647
+    assert bench.bytes_depth_sort(N) == 4 * 20 * N
+    assert bench.bytes_tile_sort(D, 13) == 2 * 20 * D and bench.bytes_tile_sort(D, 8) == 20 * D
+    b = bench.bytes_v1(N, 2_539_666, D, 1297 * 840, 16, 82 * 53, 6)
+    own = sum(b.values()) - b["radix_sort"] + bench.bytes_tile_sort(D, 13) + bench.bytes_depth_sort(N)
+    assert 4.3e9 < own < sum(b.values())
+
+
+def test_view_sharded_step_argument_checks(dgr):
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+    with pytest.raises(ValueError):
+        par.ViewShardedStep([])
+    step = par.ViewShardedStep([_settings(dgr), _settings(dgr)])
+    m, sh, op = torch.zeros(4, 3), torch.zeros(4, 16, 3), torch.zeros(4, 1)
+    sc, q = torch.ones(4, 3), torch.zeros(4, 4)
+    with pytest.raises(ValueError):       # both colour sources, as for GaussianRasterizer
+        step(means3D=m, shs=sh, colors_precomp=torch.zeros(4, 3), opacities=op, scales=sc, rotations=q)
+    with pytest.raises(RuntimeError, match="GPU"):
+        step(means3D=m, shs=sh, opacities=op, scales=sc, rotations=q)
+    assert par.shard_views(8, 1, 4) == [1, 5] and par.shard_views(8, 0, 1) == list(range(8))
+    assert isinstance(par.ViewShardedRasterizer(_settings(dgr)), par.ViewShardedStep)

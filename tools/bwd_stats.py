@@ -27,4 +27,4 @@ for t_eps in (1e-5, 0.0):
     if v[12]:
         print(f"   block-list entries {v[11]}; row-visits with the geometric block -> wave assignment {v[12]} (live {v[11]/v[12]:.3f}), with blocks "
               f"sorted by list length into groups of four {v[13]} (live {v[11]/max(v[13],1):.3f}, {v[13]/v[12]:.3f} of the visits), "
-              f"groups of eight {v[14]} (live {v[11]/max(v[14],1):.3f}); waves with any list after sorting {v[15]} of {v[0]}")
+              f"blocks with a list packed in index order into as few waves as they need {v[14]} (live {v[11]/max(v[14],1):.3f}, {v[14]/v[12]:.3f} of the visits); waves with any list after sorting {v[15]} of {v[0]}")

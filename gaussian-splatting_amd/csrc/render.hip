@@ -75,15 +75,8 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #ifndef GS_BWD_BATCH_DEF
 #define GS_BWD_BATCH_DEF 64
 #endif
-#ifndef GS_BWD_SORTED
-#define GS_BWD_SORTED 1     // blocks dealt to the waves by list length in every batch (render_bwd_kernel); 0 = fixed 8x8 sub-tiles
-#endif
-#ifndef GS_BWD_OCC
-// the sorted backward's ranking section would take 82 / 89 VGPRs (5 waves per SIMD); held at the 80 that six waves allow, no spills
-#define GS_BWD_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
-#endif
 #ifndef GS_BWD_POOL
-#define GS_BWD_POOL (GS_BWD_SORTED ? 448 : 480)     // slots of the backward's pool (0 = BATCH slots per block); measured 400..492: see render_bwd_kernel
+#define GS_BWD_POOL 480     // slots of the backward's pool (0 = BATCH slots per block); measured 400..492: see render_bwd_kernel
 #endif
 constexpr int GS_BWD_BATCH = GS_BWD_BATCH_DEF;           // pairs per backward batch (list positions are 8-bit; more than 64 pairs is untested)
 
@@ -178,7 +171,7 @@ template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint2* sid,
                                               wl_t* wl, pos_t* posmap, uint32_t dead_rows,
-                                              int* cnt_out = nullptr, bool load = true, bool pad = true) {
+                                              int* cnt_out = nullptr, bool load = true) {
     static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
     if (load && tid < n && tid < BATCH) {
@@ -259,11 +252,9 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
 #pragma unroll
         for (int q = 0; q < GS_ROWS; ++q) cnt_out[q] = cnt[q];
     }
-    if (pad) {       // (pad = false: whoever walks a list pads it -- the sorted backward hands lists to other waves)
 #pragma unroll
-        for (int q = 0; q < GS_ROWS; ++q)
-            for (int p = cnt[q] + lane; p < ((nmax + 1) & ~1); p += 64) wl[q * (BATCH + 1) + p] = (wl_t)(48u * (uint32_t)BATCH);
-    }
+    for (int q = 0; q < GS_ROWS; ++q)
+        for (int p = cnt[q] + lane; p < ((nmax + 1) & ~1); p += 64) wl[q * (BATCH + 1) + p] = (wl_t)(48u * (uint32_t)BATCH);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     return __builtin_amdgcn_readfirstlane(nmax);      // wave-uniform: keep the visit loop's bound in an SGPR
@@ -560,7 +551,7 @@ __device__ __forceinline__ void row_moments_and_totals(float pv, float c0, float
 // 0.76 -> 0.79): 0.783 -> 0.713 ms.  Pool sizes 400 / 416 / 448 / 480 / 492: 0.729 / 0.724 / 0.712 / 0.714 / 0.714 ms;
 // 496 slots cross the LDS step to 5 workgroups per CU: 0.748 ms.
 template <int BATCH, bool HAS_ZA, int POOL = 0>
-__global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
+__global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
     const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
@@ -569,7 +560,6 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
     constexpr int NW = GS_BLOCK / 64;
     constexpr int NBLK = NW * GS_ROWS;          // 16 4x4 blocks per tile
     constexpr int SLOT = 10;                    // floats per (block, list position) slot
-    constexpr bool SORTED = (GS_BWD_SORTED != 0) && POOL > 0;
     __shared__ f4 sq[3 * (BATCH + 1)];
     __shared__ uint2 sid[BATCH];                       // (4 x Gaussian index, centre of its box as x | y << 16)
     __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
@@ -581,26 +571,20 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
     constexpr int NSLOTF = POOL > 0 ? POOL * SLOT : NBLK * BSTR;
     static_assert(POOL == 0 || POOL >= NBLK, "one pair can touch all 16 blocks");
     __shared__ float slots[NSLOTF + SLOT];             // plain stores, one 40-byte slot per row visit (+ a zero slot)
-    __shared__ __attribute__((aligned(16))) uint32_t row_cnt[NBLK];   // POOL: list length of every 4x4 block, this batch
-    __shared__ uint32_t row_base[(POOL > 0 && !SORTED) ? NW : 1][NBLK];   // POOL: first slot of every block (a private copy per wave)
+    __shared__ uint32_t row_cnt[NBLK];                 // POOL: list length of every 4x4 block, this batch
+    __shared__ uint32_t row_base[POOL > 0 ? NW : 1][NBLK];   // POOL: first slot of every block (a private copy per wave)
     __shared__ __attribute__((aligned(16))) uint32_t wave_flags[NW];
-    __shared__ uint32_t walked_all[SORTED ? NBLK : NW];    // list positions walked this batch (all of them unless every pixel stopped): per wave; SORTED: per block
-    // SORTED: the 16 blocks of the tile are dealt to the waves anew in every batch, sorted by list length (four rows walk in
-    // lockstep: a wave walks the longest of its four lists), so the pixels' running state lives in LDS between batches
-    __shared__ float st_A[SORTED ? GS_BLOCK : 1], st_rem[SORTED ? GS_BLOCK : 1];   // [16 x block + pixel of the block]
-    __shared__ __attribute__((aligned(4))) uint8_t blk_dead[NBLK];   // SORTED: every pixel of the block has stopped
-    __shared__ uint32_t ord[SORTED ? NW : 1][NBLK];      // SORTED: (list length << 8 | block) at its rank, a private copy per wave
+    __shared__ uint32_t walked_all[NW];              // list positions the wave walked this batch (all of them unless every pixel stopped)
     const int tile = tile0 + tile_of_block(blockIdx.x, ntiles);
     const TileCtx c = make_ctx(tile, tiles_x, H, W);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     wl_t* wl = wl_all[wave];
     const wl_t* mylist = wl + (lane >> 4) * (BATCH + 1);
     const uint2 range = ranges[tile];
-    float fpx = (float)c.px, fpy = (float)c.py;
+    const float fpx = (float)c.px, fpy = (float)c.py;
     float gr = 0.f, gg = 0.f, gb = 0.f, gz = 0.f, ga = 0.f, total = 0.f;
-    const size_t HW = (size_t)H * W;
     if (c.inside) {
-        const size_t p = (size_t)c.py * W + c.px;
+        const size_t HW = (size_t)H * W, p = (size_t)c.py * W + c.px;
         gr = g_img[p];
         gg = g_img[HW + p];
         gb = g_img[2 * HW + p];
@@ -610,17 +594,8 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
                 ga * out_alpha[p];
     }
     float A = 0.f, T = 1.f, rem = total;
-    f2 g_rg = {gr, gg}, g_bz = {gb, gz};
+    const f2 g_rg = {gr, gg}, g_bz = {gb, gz};
     uint32_t P = c.inside ? ((uint32_t)c.px | (uint32_t)c.py << 16) : P_STOPPED;
-    int cur_b = wave * GS_ROWS + (lane >> 4);           // SORTED: the block whose pixels this row holds (geometric at first)
-    const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
-    if (SORTED) {
-        // pixels outside the image start with A = 1: stopped at every t_eps, like P_STOPPED
-        st_A[cur_b * 16 + (lane & 15)] = c.inside ? 0.0f : 1.0f;
-        st_rem[cur_b * 16 + (lane & 15)] = total;
-        const uint64_t out = __builtin_amdgcn_ballot_w64(!c.inside);
-        if ((lane & 15) == 0) blk_dead[cur_b] = (((out >> (lane & 48)) & 0xFFFFull) == 0xFFFFull) ? 1 : 0;
-    }
     // which of the 10 values this lane holds after row_reduce_scatter10 (-1: a duplicate)
     const int t = lane & 3, bank = (lane >> 2) & 3;
     int red_slot = -1;
@@ -648,90 +623,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
         if (block_all(P == P_STOPPED, wave_flags)) break;
         n = min((int)(range.y - base), BATCH);
         int nmax;
-        const wl_t* list_now = mylist;
-        if constexpr (SORTED) {
-            // dead rows of the blocks THIS wave culls (its 8x8 sub-tile), as left by whoever walked them last
-            const uint32_t dv = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(blk_dead)[wave]);
-            const uint32_t dead = (dv & 1u) | ((dv >> 7) & 2u) | ((dv >> 14) & 4u) | ((dv >> 21) & 8u);
-            const int i16 = lane & 15, q = lane >> 4;
-            uint32_t rank, m0, m1, m2, m3, mine;
-            for (bool first = true;; first = false) {
-                int cq[GS_ROWS];
-                stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave], dead, cq, first,
-                                      /*pad=*/false);
-                if (lane < GS_ROWS) row_cnt[wave * GS_ROWS + lane] = (uint32_t)cq[lane];
-                __syncthreads();
-                // rank of block i16 among the 16 list lengths, longest first, ties by block index: every row of the wave
-                // compares its block against four of the others, the four partial counts are added up across the rows
-                const uint32_t key = (row_cnt[i16] << 4) | (uint32_t)(15 - i16);
-                const uint4 c4 = reinterpret_cast<const uint4*>(row_cnt)[q];
-                const uint32_t k0 = (c4.x << 4) | (uint32_t)(15 - 4 * q), k1 = (c4.y << 4) | (uint32_t)(14 - 4 * q),
-                               k2 = (c4.z << 4) | (uint32_t)(13 - 4 * q), k3 = (c4.w << 4) | (uint32_t)(12 - 4 * q);
-                uint32_t part = (uint32_t)(k0 > key) + (uint32_t)(k1 > key) + (uint32_t)(k2 > key) + (uint32_t)(k3 > key);
-                part += (uint32_t)__shfl_xor((int)part, 16);
-                part += (uint32_t)__shfl_xor((int)part, 32);
-                rank = part;
-#ifdef GS_SORT_IDENTITY
-                rank = (uint32_t)i16;        // timing experiment: the infrastructure with the fixed assignment
-#endif
-                if (lane < NBLK) ord[wave][rank] = (key >> 4 << 8) | (uint32_t)i16;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // the wave with index w walks the blocks of ranks 4w .. 4w + 3: as many positions as the longest of them has
-                m0 = ord[wave][0] >> 8; m1 = ord[wave][4] >> 8; m2 = ord[wave][8] >> 8; m3 = ord[wave][12] >> 8;
-                mine = ord[wave][4 * wave + q];
-                if (4 * (m0 + m1 + m2 + m3) <= (uint32_t)POOL || n == 1) break;
-                GS_STAT(10, 1);
-                n = n > 1 ? n / 2 : 1;
-                __syncthreads();        // everybody has read row_cnt and the lists before they are rebuilt
-            }
-            nmax = __builtin_amdgcn_readfirstlane((int)(wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3));
-            // first slot of a block: the groups before its own, then its place in the group
-            const auto slot_base = [&](uint32_t r) {
-                const uint32_t g = r >> 2;
-                const uint32_t before = g == 0 ? 0u : g == 1 ? m0 : g == 2 ? m0 + m1 : m0 + m1 + m2;
-                const uint32_t own = g == 0 ? m0 : g == 1 ? m1 : g == 2 ? m2 : m3;
-                return 4u * before + (r & 3u) * own;
-            };
-            flush_base = slot_base(rank);                                       // block tid & 15 = lane & 15
-            const int my_b = (int)(mine & 0xFFu);
-            const int my_cnt = (int)(mine >> 8);
-            my_slot = slots + (size_t)slot_base((uint32_t)(4 * wave + q)) * SLOT + (vis_slot < 0 ? 0 : vis_slot);
-            wl_t* my_wl = wl_all[my_b >> 2] + (my_b & 3) * (BATCH + 1);
-            list_now = my_wl;
-            // pad the list up to the (even) length this wave walks with the record no lane is ever inside
-            for (int p = my_cnt + i16; p < ((nmax + 1) & ~1); p += 16) my_wl[p] = (wl_t)(48u * (uint32_t)BATCH);
-            // this row's pixels: running state from LDS; position and upstream gradient only when the block changed
-            A = st_A[my_b * 16 + i16];
-            rem = st_rem[my_b * 16 + i16];
-            T = 1.0f - A;
-#ifdef GS_SORT_NO_G
-            if (false) {                     // timing experiment (wrong gradients): no reload of the upstream gradient
-#else
-            if (my_b != cur_b) {
-#endif
-                const int px = tile_x0 + ((my_b >> 2) & 1) * GS_SUB + (my_b & 1) * GS_QUAD + (i16 & 3);
-                const int py = tile_y0 + (my_b >> 3) * GS_SUB + ((my_b >> 1) & 1) * GS_QUAD + (i16 >> 2);
-                fpx = (float)px;
-                fpy = (float)py;
-                gr = gg = gb = gz = ga = 0.f;
-                if (px < W && py < H) {
-                    const size_t p = (size_t)py * W + px;
-                    gr = g_img[p];
-                    gg = g_img[HW + p];
-                    gb = g_img[2 * HW + p];
-                    if (HAS_ZA && g_depth) gz = g_depth[p];
-                    if (HAS_ZA && g_alpha) ga = g_alpha[p];
-                }
-                g_rg = f2{gr, gg};
-                g_bz = f2{gb, gz};
-                cur_b = my_b;
-            }
-            // a stopped pixel (1 - A <= t_eps: also every pixel outside the image, which starts at A = 1) fails every box test
-            P = T <= t_eps ? P_STOPPED : ((uint32_t)(int)fpx | (uint32_t)(int)fpy << 16);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } else if (POOL > 0) {
+        if (POOL > 0) {
             const uint32_t dead = dead_row_mask(P);
             for (bool first = true;; first = false) {
 #ifdef GS_STATS
@@ -759,19 +651,17 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
                 if (total <= (uint32_t)POOL || n == 1) {
 #ifdef GS_STATS
                     if (tid == 0) {       // what a sorted block -> wave assignment would walk
-                        int cs[NBLK], live = 0, geo = 0, srt = 0, srt8 = 0;
+                        int cs[NBLK], live = 0, geo = 0, srt = 0;
                         for (int i = 0; i < NBLK; ++i) { cs[i] = stat_cnt[i]; live += cs[i]; }
                         for (int w = 0; w < NW; ++w) geo += 4 * max(max(cs[4 * w], cs[4 * w + 1]), max(cs[4 * w + 2], cs[4 * w + 3]));
                         {   // blocks with a list packed, in index order, into as few waves as they need (no sorting by length)
                             int pk = 0, g = 0, k = 0;
                             for (int i = 0; i < NBLK; ++i) if (cs[i] > 0) { g = max(g, cs[i]); if (++k == 4) { pk += 4 * g; g = 0; k = 0; } }
                             pk += 4 * g;
-                            atomicAdd(&gs_dbg[9], 0ull);
                             atomicAdd(&gs_dbg[14], (unsigned long long)pk);
                         }
                         for (int i = 1; i < NBLK; ++i) { const int v = cs[i]; int j = i; while (j > 0 && cs[j - 1] < v) { cs[j] = cs[j - 1]; --j; } cs[j] = v; }
                         for (int w = 0; w < NW; ++w) srt += 4 * cs[4 * w];
-                        (void)srt8;
                         atomicAdd(&gs_dbg[11], (unsigned long long)live);
                         atomicAdd(&gs_dbg[12], (unsigned long long)geo);
                         atomicAdd(&gs_dbg[13], (unsigned long long)srt);
@@ -794,7 +684,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
             nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
                                          dead_row_mask(P));
         }
-        uint32_t lp = lds_addr_of(list_now);
+        uint32_t lp = lds_addr_of(mylist);
         uint32_t off_next = list_read<0>(lp);
         GS_STAT(0, 1); GS_STAT(1, nmax); GS_STAT(8, n);
         // two visits per trip (list pointer and slot pointer advance once, the second visit uses immediate offsets); an odd
@@ -851,28 +741,18 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
             visit(kk, IntC<sizeof(wl_t)>());
             visit(kk + 1, IntC<2 * sizeof(wl_t)>());
         }
-        if constexpr (SORTED) {
-            // hand the pixels back: state, how far the block's list was walked, and whether the block is done for good
-            st_A[cur_b * 16 + (lane & 15)] = A;
-            st_rem[cur_b * 16 + (lane & 15)] = rem;
-            const uint64_t stopped = __builtin_amdgcn_ballot_w64(P == P_STOPPED);
-            if ((lane & 15) == 0) {
-                walked_all[cur_b] = (uint32_t)min(kk, nmax);
-                blk_dead[cur_b] = (((stopped >> (lane & 48)) & 0xFFFFull) == 0xFFFFull) ? 1 : 0;
-            }
-        } else {
-            if (lane == 0) walked_all[wave] = (uint32_t)min(kk, nmax);
-        }
+        if (lane == 0) walked_all[wave] = (uint32_t)min(kk, nmax);
         __syncthreads();
         // flush: the 16 lanes of a DPP row take one pair, lane b the sums of 4x4 block b (moved from the block's
         // origin to the centre of the Gaussian's box); the 22-add row reduce-scatter adds the 16 blocks up and ten
         // lanes add one value each to the Gaussian's row: sum pv {dx, dy, dx^2, dx dy, dy^2, 1} and the four
         // colour / depth totals.  The conic and opacity factors are applied by gs_preprocess_bwd.
         const int blk = tid & 15;
-        const uint32_t blk_walked = walked_all[SORTED ? blk : blk >> 2];
+        const uint32_t blk_walked = walked_all[blk >> 2];
         const pos_t* blk_posmap = posmap_all[blk >> 2] + (blk & 3) * BATCH;
         const float* blk_slots = POOL > 0 ? slots + (size_t)flush_base * SLOT : slots + (size_t)blk * BSTR;
         // origin of 4x4 block blk = 4 wave + row (make_ctx)
+        const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
         const float blk_x = (float)(tile_x0 + ((blk >> 2) & 1) * GS_SUB + (blk & 1) * GS_QUAD);
         const float blk_y = (float)(tile_y0 + (blk >> 3) * GS_SUB + ((blk >> 1) & 1) * GS_QUAD);
 #pragma unroll

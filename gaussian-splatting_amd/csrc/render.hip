@@ -75,9 +75,6 @@ constexpr int GS_QUAD = 4;                 // edge of a row's pixel block
 #ifndef GS_BWD_BATCH_DEF
 #define GS_BWD_BATCH_DEF 64
 #endif
-#ifndef GS_BWD_FLUSH
-#define GS_BWD_FLUSH 2      // 1: sixteen lanes per pair (one per block) + row reduce-scatter; 2: two levels (per wave, then per tile)
-#endif
 #ifndef GS_BWD_POOL
 #define GS_BWD_POOL 480     // slots of the backward's pool (0 = BATCH slots per block); measured 400..492: see render_bwd_kernel
 #endif
@@ -174,7 +171,7 @@ template <int BATCH>
 __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, const uint32_t* __restrict__ point_list,
                                               uint32_t base, int n, const TileCtx& c, f4* sq, uint2* sid,
                                               wl_t* wl, pos_t* posmap, uint32_t dead_rows,
-                                              int* cnt_out = nullptr, bool load = true, uint32_t* posmap32 = nullptr) {
+                                              int* cnt_out = nullptr, bool load = true) {
     static_assert(BATCH % 16 == 0 && BATCH >= 16 && BATCH <= GS_BLOCK, "one staging lane per pair");
     const int tid = threadIdx.x;
     if (load && tid < n && tid < BATCH) {
@@ -240,17 +237,14 @@ __device__ __forceinline__ int stage_and_cull(const f4* __restrict__ splat, cons
         }
         const bool hit[GS_ROWS] = {hx0 && hy0 && !(dead_rows & 1u), hx1 && hy0 && !(dead_rows & 2u),
                                    hx0 && hy1 && !(dead_rows & 4u), hx1 && hy1 && !(dead_rows & 8u)};
-        uint32_t packed = 0;
 #pragma unroll
         for (int q = 0; q < GS_ROWS; ++q) {
             const uint64_t m = __builtin_amdgcn_ballot_w64(hit[q]);     // (the lane mask itself; __ballot goes through a select and a compare)
             const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (hit[q]) wl[q * (BATCH + 1) + pos] = (wl_t)(48u * (uint32_t)j);
             if (posmap && j < BATCH) posmap[q * BATCH + j] = hit[q] ? (pos_t)pos : POS_NONE;
-            packed |= (hit[q] ? (uint32_t)pos : (uint32_t)POS_NONE) << (8 * q);
             cnt[q] += __popcll(m);
         }
-        if (posmap32 && j < BATCH) posmap32[j] = packed;      // the same four positions as one word per pair (two-level flush)
     }
     }
     const int nmax = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
@@ -556,11 +550,8 @@ __device__ __forceinline__ void row_moments_and_totals(float pv, float c0, float
 // batches to stage, cull and synchronise, and four lists twice as long are walked in lockstep with less waste (live rows
 // 0.76 -> 0.79): 0.783 -> 0.713 ms.  Pool sizes 400 / 416 / 448 / 480 / 492: 0.729 / 0.724 / 0.712 / 0.714 / 0.714 ms;
 // 496 slots cross the LDS step to 5 workgroups per CU: 0.748 ms.
-#ifndef GS_BWD_OCC
-#define GS_BWD_OCC
-#endif
 template <int BATCH, bool HAS_ZA, int POOL = 0>
-__global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
+__global__ __launch_bounds__(GS_BLOCK) void render_bwd_kernel(
     int H, int W, int tiles_x, int tile0, int ntiles, const float4* __restrict__ splat, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ aux_rgb,
     const float* __restrict__ out_depth, const float* __restrict__ out_alpha, const float* __restrict__ g_img,
@@ -572,10 +563,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
     __shared__ f4 sq[3 * (BATCH + 1)];
     __shared__ uint2 sid[BATCH];                       // (4 x Gaussian index, centre of its box as x | y << 16)
     __shared__ wl_t wl_all[NW][GS_ROWS * (BATCH + 1)];
-    constexpr bool FLUSH2 = (GS_BWD_FLUSH == 2) && POOL > 0 && BATCH > 32;
-    __shared__ pos_t posmap_all[FLUSH2 ? 1 : NW][FLUSH2 ? 1 : GS_ROWS * BATCH];
-    __shared__ uint32_t posmap32_all[FLUSH2 ? NW : 1][FLUSH2 ? BATCH : 1];   // FLUSH2: the four list positions of a pair as one word
-    __shared__ __attribute__((aligned(4))) uint8_t pair_any[FLUSH2 ? BATCH : 1][4];   // FLUSH2: wave w holds sums for the pair
+    __shared__ pos_t posmap_all[NW][GS_ROWS * BATCH];
 #ifndef GS_SLOT_PAD
 #define GS_SLOT_PAD 4      // measured: 0.8135 ms -> 0.7975 ms (rows of a wave start in different banks)
 #endif
@@ -641,19 +629,16 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
 #ifdef GS_STATS
                 __shared__ int stat_cnt[NBLK];
                 int cq[GS_ROWS];
-                nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl,
-                                             FLUSH2 ? nullptr : posmap_all[FLUSH2 ? 0 : wave], dead, cq, first,
-                                             FLUSH2 ? posmap32_all[FLUSH2 ? wave : 0] : nullptr);
+                nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave], dead,
+                                             cq, first);
                 if (lane < GS_ROWS) stat_cnt[wave * GS_ROWS + lane] = cq[lane];
 #else
-                nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl,
-                                             FLUSH2 ? nullptr : posmap_all[FLUSH2 ? 0 : wave], dead, nullptr, first,
-                                             FLUSH2 ? posmap32_all[FLUSH2 ? wave : 0] : nullptr);
+                nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave], dead,
+                                             nullptr, first);
 #endif
                 // every row of a wave gets the wave's longest list: a wave walks nmax positions with all four rows, and a
                 // row whose own list is shorter still stores (zeros) at the positions behind it
-                // (FLUSH2: at least 16 slots per row, so that a wave's region of the pool also holds its 64 x 10 partial sums)
-                if (lane < GS_ROWS) row_cnt[wave * GS_ROWS + lane] = (uint32_t)(FLUSH2 ? max(nmax, 16) : nmax);
+                if (lane < GS_ROWS) row_cnt[wave * GS_ROWS + lane] = (uint32_t)nmax;
                 __syncthreads();
                 // inclusive scan of the 16 list lengths, in every 16-lane row alike (DPP row shifts: no LDS round trips)
                 const uint32_t own = row_cnt[lane & 15];
@@ -696,7 +681,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
                 __syncthreads();        // everybody has read row_cnt and the lists before they are rebuilt
             }
         } else {
-            nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[FLUSH2 ? 0 : wave],
+            nmax = stage_and_cull<BATCH>((const f4*)splat, point_list, base, n, c, sq, sid, wl, posmap_all[wave],
                                          dead_row_mask(P));
         }
         uint32_t lp = lds_addr_of(mylist);
@@ -755,88 +740,6 @@ __global__ __launch_bounds__(GS_BLOCK) GS_BWD_OCC void render_bwd_kernel(
             if ((kk & 7) == 0 && __all(P == P_STOPPED)) break;
             visit(kk, IntC<sizeof(wl_t)>());
             visit(kk + 1, IntC<2 * sizeof(wl_t)>());
-        }
-        if constexpr (FLUSH2) {
-            // Two-level flush.  Level 1, per wave, no barrier before it (a wave reads only its own slots, its own position map
-            // and the staged pair table): lane j takes pair j of the batch, adds up what this wave's four blocks hold for it
-            // -- each block's local moments moved to the centre of the Gaussian's box first (small exact integers, see below)
-            // -- and leaves the ten sums in the wave's own region of the pool (every row owns at least 16 slots, so the
-            // region holds 64 x 10 floats; LDS operations of one wave complete in order, so the stores land after every
-            // lane's reads).  Level 2, after the one barrier: ten lanes per pair add the four waves' sums in a fixed order
-            // and issue the row atomics.  Against sixteen lanes per pair + a 22-add reduce-scatter: no lane is spent on
-            // a block that a pair does not touch in level 2, and level 1 walks four blocks per lane instead of one.
-            const uint32_t walked = (uint32_t)min(kk, nmax);
-            const uint32_t rs = (uint32_t)max(nmax, 16);                                            // slots per row of this wave
-            const uint32_t reg0 = (uint32_t)__builtin_amdgcn_readlane((int)flush_base, 0), reg1 = (uint32_t)__builtin_amdgcn_readlane((int)flush_base, 4),
-                           reg2 = (uint32_t)__builtin_amdgcn_readlane((int)flush_base, 8), reg3 = (uint32_t)__builtin_amdgcn_readlane((int)flush_base, 12);
-            const uint32_t my_reg = wave == 0 ? reg0 : wave == 1 ? reg1 : wave == 2 ? reg2 : reg3;   // first slot of this wave's region
-            {
-                const uint32_t pm = posmap32_all[FLUSH2 ? wave : 0][lane];
-                const uint2 idc = sid[lane];
-                const float ex0 = (float)c.sx0 - (float)(idc.y & 0xFFFFu), ey0 = (float)c.sy0 - (float)(idc.y >> 16);
-                float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                bool anyv = false;
-#ifdef GS_F2_UNROLL1
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
-                for (int q = 0; q < GS_ROWS; ++q) {
-                    const uint32_t pos = (pm >> (8 * q)) & 0xFFu;
-                    // row q holds sums for the pair if the pair is in its list at a position the wave walked (POS_NONE = 255 is
-                    // behind every list; pairs behind n are in no list)
-                    const bool valid = pos < walked;
-                    GS_STAT(6, 1);
-                    if (!__any(valid)) continue;
-                    GS_STAT(7, 1); GS_STAT(9, __popcll(__ballot(valid)));
-                    anyv = anyv || valid;
-                    const float* sl = valid ? slots + (size_t)(my_reg + (uint32_t)q * rs + pos) * SLOT : slots + NSLOTF;
-                    float m[10];
-#pragma unroll
-                    for (int k = 0; k < 10; ++k) m[k] = sl[k];
-                    // the block's local moments -> moments of pv about the CENTRE OF THE GAUSSIAN'S BOX (an integer pixel that
-                    // every tile derives identically): dx_o = (block origin - centre) + lx with small exact integers, so
-                    // nothing is lost here however far away the mean is; gs_preprocess_bwd moves the sums to the mean, in
-                    // double, once per Gaussian
-                    const float ex = (q & 1) ? ex0 + (float)GS_QUAD : ex0, ey = (q >> 1) ? ey0 + (float)GS_QUAD : ey0;
-                    const float exM = ex * m[0], eyM = ey * m[0];
-                    acc[0] += exM + m[1];
-                    acc[1] += eyM + m[3];
-                    acc[2] += __builtin_fmaf(ex, exM + 2.0f * m[1], m[2]);
-                    acc[3] += __builtin_fmaf(ex, eyM + m[3], m[4]) + ey * m[1];
-                    acc[4] += __builtin_fmaf(ey, eyM + 2.0f * m[3], m[5]);
-                    acc[5] += m[0];
-                    acc[6] += m[6];
-                    acc[7] += m[7];
-                    acc[8] += m[8];
-                    acc[9] += m[9];
-                }
-                float* part = slots + (size_t)my_reg * SLOT + lane * SLOT;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) part[k] = acc[k];
-                pair_any[lane][wave] = anyv ? 1 : 0;
-            }
-            __syncthreads();
-            {
-                const int k = lane & 15;                 // which of the ten sums (0..5 doubles, 6..9 floats of the gradient row)
-                const float* r0 = slots + (size_t)reg0 * SLOT + k, * r1 = slots + (size_t)reg1 * SLOT + k,
-                           * r2 = slots + (size_t)reg2 * SLOT + k, * r3 = slots + (size_t)reg3 * SLOT + k;
-                char* const row0 = reinterpret_cast<char*>(grad_rows) + (k < 6 ? 8 * k : 4 * (6 + k));
-#pragma unroll
-                for (int r = 0; r < BATCH / 16; ++r) {
-                    const int j = r * 16 + (tid >> 4);
-                    const bool any = *reinterpret_cast<const uint32_t*>(pair_any[j]) != 0u;
-                    if (!__any(any)) continue;           // wave-uniform: none of this wave's four pairs was walked anywhere
-                    if (any && k < (HAS_ZA ? 10 : 9)) {
-                        const float sum = ((r0[j * SLOT] + r1[j * SLOT]) + r2[j * SLOT]) + r3[j * SLOT];
-                        // sid[j].x = 4 x Gaussian index (staging): a row is 64 bytes = 16 x that (one v_lshl_add_u64)
-                        char* dst = row0 + ((uint64_t)sid[j].x << 4);
-                        if (k < 6) atomicAdd(reinterpret_cast<double*>(dst), (double)sum);
-                        else atomicAdd(reinterpret_cast<float*>(dst), sum);
-                    }
-                }
-            }
-            continue;
         }
         if (lane == 0) walked_all[wave] = (uint32_t)min(kk, nmax);
         __syncthreads();

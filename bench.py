@@ -218,7 +218,8 @@ def main():
             params = {k: getattr(scene, k).to(dev).requires_grad_(True) for k in names}
             # several views per step: config 4's step (8 views, all ranks together) by default once there is an exchange
             # to amortise; a single GPU renders one frame per step unless asked otherwise
-            step_views = vps if vps is not None else (8 if (mode == "allreduce" and world > 1 and 8 >= world) else world)
+            if mode != "tile_rows":     # (tile-row sharding cuts ONE frame: step_views stays 1)
+                step_views = vps if vps is not None else (8 if (mode == "allreduce" and world > 1 and 8 >= world) else world)
             if mode == "allreduce" or step_views > world:
                 my_ids = par.shard_views(step_views, rank, world)
                 my_views = [make_settings(syn.jitter_view(scene, v) if (multi or step_views > 1) else scene) for v in my_ids]

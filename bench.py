@@ -443,7 +443,7 @@ def main():
                        "parallelism": {"single": "single", "tile_rows": f"tile_rows{world}",
                                        "exchange": f"views{world}+gaussians_sharded{world}(splat exchange)",
                                        "allreduce": f"views{step_views}over{world}ranks+gaussians_replicated(one bucketed grad "
-                                                    f"all-reduce per step, overlapped with the last view's preprocess_bwd, "
+                                                    f"all-reduce per step, overlapped with the views' one preprocess_bwd launch per range, "
                                                     f"{args.buckets} buckets)"}[mode],
                        "parallel_arg": args.parallel},
             "roofline": roofline,

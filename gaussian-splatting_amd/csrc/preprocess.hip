@@ -14,6 +14,7 @@
 // HBM-bound: algorithmic bytes per Gaussian are 40 (mean, scale, rotation) + 4 (opacity)
 // + 12 K (SH) read and 48 (record) + 8 (radii, tiles_touched) written.
 #include "gsplat_common.h"
+#include "../../include/gsplat.h"
 
 namespace {
 
@@ -420,6 +421,279 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 constexpr int BWD_STAGE_MAX_ROW = 48;
 constexpr int BWD_STAGE_STRIDE = BWD_STAGE_MAX_ROW + 1;   // odd stride: per-lane rows hit all banks
 
+// What one view contributes to one drawn Gaussian's gradients (everything but the SH coefficients' own gradient, which
+// goes to st_row / gsh_out).  Shared by the single-view kernel and the multi-view kernel below.
+struct BwdGrads {
+    float gm[3], gm2[2], gs[3], gq[4], gc6[6], gop, gcol[3];
+};
+
+// What bwd_one_view reads of one (Gaussian, view) besides the Gaussian itself; requested by bwd_request, apart from the
+// chain rule, so that a caller can have the next view's values travel while this view's are used.
+struct BwdInputs {
+    float4 r0, r1, r2, r3;     // the gradient row: 6 doubles (moments of pv about the box centre) + floats 12..15 (rgb, depth): gsplat_common.h
+    float4 j0, j1, j2;         // the colour side-table row (JAC)
+    float opacity;
+};
+
+template <int PART, bool JAC>
+__device__ __forceinline__ BwdInputs bwd_request(int i, const float* __restrict__ opacities,
+                                                 const float4* __restrict__ grad_rows, const float4* __restrict__ sh_jac) {
+    static_assert(GS_GRAD_ROW == 16, "row layout");
+    const float4* row = grad_rows + (GS_GRAD_ROW / 4) * (size_t)i;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    BwdInputs in;
+    in.r0 = PART != 2 ? row[0] : z4; in.r1 = PART != 2 ? row[1] : z4; in.r2 = PART != 2 ? row[2] : z4; in.r3 = row[3];
+    in.opacity = PART != 2 ? opacities[i] : 0.0f;
+    in.j0 = in.j1 = in.j2 = z4;
+    if (JAC) {
+        const float4* jp = sh_jac + 3 * (size_t)i;
+        in.j0 = jp[0]; in.j1 = jp[1]; in.j2 = jp[2];
+    }
+    return in;
+}
+
+// STAGE_ADD (staged form only): st_row holds the sum over the views before this one; add to it instead of overwriting.
+// Returns the number of SH gradient floats written for this Gaussian.
+template <int DEG, int MODE, int PART, bool JAC, bool STAGE_ADD>
+__device__ __forceinline__ int bwd_one_view(const BwdInputs& in, 
+    int i, int K, int H, int W, const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ campos, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rots, const float* __restrict__ cov6, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, float* st_row, float* gsh_out, bool acc, BwdGrads& o) {
+    constexpr bool VEC4 = MODE >= 1;
+    constexpr bool STAGE = MODE == 2;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float (&gm)[3] = o.gm;
+    float (&gm2)[2] = o.gm2;
+    float (&gs)[3] = o.gs;
+    float (&gq)[4] = o.gq;
+    float (&gc6)[6] = o.gc6;
+    float& gop = o.gop;
+    float (&gcol)[3] = o.gcol;
+    int sh_written = 0;
+    const float4 r0 = in.r0, r1 = in.r1, r2 = in.r2, r3 = in.r3, j0 = in.j0, j1 = in.j1, j2 = in.j2;
+    const float opacity_i = in.opacity;
+    Geom g;
+    if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
+    const auto dbl = [](float lo, float hi) {
+        return __hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo));
+    };
+    float d_mx = 0.f, d_my = 0.f, d_a = 0.f, d_b = 0.f, d_d = 0.f, d_op = 0.f;
+    const float d_r = r3.x, d_g = r3.y, d_bl = r3.z, d_z = r3.w;
+    if (PART != 2) {
+        // moments of q = opacity * pv about the mean, from the moments of pv about the box centre (double: the
+        // shift can be thousands of pixels for a splat whose mean is far off screen)
+        const double op = (double)opacity_i;
+        const double M0 = dbl(r2.z, r2.w);
+        const double ex = (double)((g.xmin + g.xmax - 1) >> 1) - (double)g.mx;
+        const double ey = (double)((g.ymin + g.ymax - 1) >> 1) - (double)g.my;
+        const double S1x = dbl(r0.x, r0.y), S1y = dbl(r0.z, r0.w);
+        const double Sx = op * (ex * M0 + S1x), Sy = op * (ey * M0 + S1y);
+        const double Sxx = op * (ex * (ex * M0 + 2.0 * S1x) + dbl(r1.x, r1.y));
+        const double Sxy = op * (ex * (ey * M0 + S1y) + ey * S1x + dbl(r1.z, r1.w));
+        const double Syy = op * (ey * (ey * M0 + 2.0 * S1y) + dbl(r2.x, r2.y));
+        // power = -0.5 (a dx^2 + 2 b dx dy + d dy^2), dx = pixel - mean (reference :417-424)
+        d_mx = (float)((double)g.ca * Sx + (double)g.cb * Sy);
+        d_my = (float)((double)g.cd * Sy + (double)g.cb * Sx);
+        d_a = (float)(-0.5 * Sxx);
+        d_b = (float)(-0.5 * Sxy);
+        d_d = (float)(-0.5 * Syy);
+        d_op = (float)M0;
+    }
+    gop = d_op;
+    gm2[0] = d_mx;
+    gm2[1] = d_my;
+    float px, py, pz;            // (the projection has loaded the mean already: a second load here was a second wait)
+    if (PART != 2) { px = g.pos[0]; py = g.pos[1]; pz = g.pos[2]; }
+    else { px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2]; }
+    // ---- colour
+    if (colors_precomp) {
+        gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
+    } else if (shs && PART != 1) {
+        float b[NB];
+        const float vx = px - campos[0], vy = py - campos[1], vz = pz - campos[2];
+        const float n = sqrtf(vx * vx + vy * vy + vz * vz);
+        const float ne = n + 1e-7f;
+        const float dx = vx / ne, dy = vy / ne, dz = vz / ne;
+        sh_basis<DEG>(dx, dy, dz, b);
+        const float dcol[3] = {d_r, d_g, d_bl};
+        float gcl[3];
+        float ddir[3] = {0.f, 0.f, 0.f};
+        if (JAC) {
+            // W = d colour / d dir and the clamp mask as the forward left them
+            const float Wm[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
+            const uint32_t pass = __float_as_uint(j2.y);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                gcl[c] = ((pass >> c) & 1u) ? dcol[c] : 0.0f;
+#pragma unroll
+                for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
+            }
+        } else {
+        float bg[NB][3];
+        sh_basis_grad<DEG>(dx, dy, dz, bg);
+        // one streaming pass over the coefficients (each loaded value is consumed at once, so the
+        // 48 floats never sit in registers together): colour v[c] = sum_k b_k sh_kc and
+        // Wm[a][c] = sum_k (d b_k / d dir_a) sh_kc; the clamp mask is applied afterwards
+        float vcol[3] = {0.f, 0.f, 0.f};
+        float Wm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        {
+            const float* p = shs + (size_t)i * K * 3;
+            constexpr int NF = NB * 3;
+            constexpr int NV = (VEC4 && !STAGE) ? (NF + 3) / 4 : 0;
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            float4 t4[NV > 0 ? NV : 1];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) t4[v] = p4[v];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma clang fp contract(off)     // the colour must round as in the forward (clamp mask)
+                float val;
+                if (STAGE) {
+                    val = st_row[f];
+                } else if (VEC4) {
+                    const float4 t = t4[f / 4];
+                    val = (f % 4 == 0) ? t.x : (f % 4 == 1) ? t.y : (f % 4 == 2) ? t.z : t.w;
+                } else {
+                    val = p[f];
+                }
+                const int k = f / 3, c = f % 3;
+                vcol[c] += b[k] * val;
+                Wm[0][c] += bg[k][0] * val;
+                Wm[1][c] += bg[k][1] * val;
+                Wm[2][c] += bg[k][2] * val;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = vcol[c] + 0.5f;
+            gcl[c] = (v >= 0.0f && v <= 1.0f) ? dcol[c] : 0.0f;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
+        }
+        }
+        if (gsh_out && STAGE) {
+#pragma unroll
+            for (int f = 0; f < NB * 3; ++f) st_row[f] = b[f / 3] * gcl[f % 3] + (STAGE_ADD ? st_row[f] : 0.0f);
+            sh_written = NB * 3;
+        } else if (gsh_out) {
+            if (VEC4) {   // 16-byte stores: a quarter of the partial-line write requests
+                constexpr int NV = (NB * 3) / 4;      // whole float4s; the 0..3 floats left go scalar
+                float4* o4 = reinterpret_cast<float4*>(gsh_out);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = b[(4 * v + e) / 3] * gcl[(4 * v + e) % 3];
+                    if (acc) {
+                        const float4 o = o4[v];
+                        t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
+                    }
+                    o4[v] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+#pragma unroll
+                for (int f = 4 * NV; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3] + (acc ? gsh_out[f] : 0.0f);
+            } else {
+#pragma unroll
+                for (int f = 0; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3] + (acc ? gsh_out[f] : 0.0f);
+            }
+            sh_written = NB * 3;
+        }
+        if (n > 0.0f) {
+            const float dot = ddir[0] * vx + ddir[1] * vy + ddir[2] * vz;
+            const float k2 = dot / (ne * ne * n);
+            gm[0] += ddir[0] / ne - vx * k2;
+            gm[1] += ddir[1] / ne - vy * k2;
+            gm[2] += ddir[2] / ne - vz * k2;
+        } else {
+            gm[0] += ddir[0] / ne; gm[1] += ddir[1] / ne; gm[2] += ddir[2] / ne;
+        }
+    }
+    if (PART != 2) {
+    // ---- screen mean
+    {
+        const float wden = g.clip[3] + 1e-7f;
+        const float dnx = 0.5f * (float)W * d_mx, dny = 0.5f * (float)H * d_my;
+        const float dcx = dnx / wden, dcy = dny / wden;
+        const float dcw = -(dnx * g.clip[0] + dny * g.clip[1]) / (wden * wden);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gm[c] += proj[c] * dcx + proj[4 + c] * dcy + proj[12 + c] * dcw;
+    }
+    // ---- conic -> cov2D
+    const float d_inv_det = d_a * g.c11 - 2.0f * d_b * g.c01 + d_d * g.c00;
+    const float d_det = -g.inv_det * g.inv_det * d_inv_det;
+    float G2[2][2];
+    G2[0][0] = d_d * g.inv_det + d_det * g.c11;
+    G2[1][1] = d_a * g.inv_det + d_det * g.c00;
+    G2[0][1] = -d_b * g.inv_det - d_det * g.c01;
+    G2[1][0] = G2[0][1];
+    // ---- cov2D = J Sigma J^T
+    const float J[2][3] = {{g.j00, 0.0f, g.j02}, {0.0f, g.j11, g.j12}};
+    float dS[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) v += J[r][a] * G2[r][c] * J[c][b2];
+            dS[a][b2] = v;
+        }
+    float JS[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            JS[r][c] = J[r][0] * g.S[0][c] + J[r][1] * g.S[1][c] + J[r][2] * g.S[2][c];
+    float dJ[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            dJ[r][c] = (G2[r][0] + G2[0][r]) * JS[0][c] + (G2[r][1] + G2[1][r]) * JS[1][c];
+    const float focal_x = proj[0] * (float)W / 2.0f, focal_y = proj[5] * (float)H / 2.0f;
+    const float x = g.cam[0], y = g.cam[1], z = g.cam[2];
+    const float zi = z + 1e-7f, z2 = z * z + 1e-7f;
+    float dcam[3];
+    dcam[0] = dJ[0][2] * (-focal_x / z2);
+    dcam[1] = dJ[1][2] * (-focal_y / z2);
+    dcam[2] = dJ[0][0] * (-focal_x / (zi * zi)) + dJ[1][1] * (-focal_y / (zi * zi)) +
+              dJ[0][2] * (x * focal_x * 2.0f * z / (z2 * z2)) +
+              dJ[1][2] * (y * focal_y * 2.0f * z / (z2 * z2)) + d_z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        gm[c] += view[c] * dcam[0] + view[4 + c] * dcam[1] + view[8 + c] * dcam[2];
+    if (cov6) {
+        gc6[0] = dS[0][0]; gc6[1] = dS[0][1] + dS[1][0]; gc6[2] = dS[0][2] + dS[2][0];
+        gc6[3] = dS[1][1]; gc6[4] = dS[1][2] + dS[2][1]; gc6[5] = dS[2][2];
+    } else {
+        const float s[3] = {g.scl[0], g.scl[1], g.scl[2]};     // as the projection loaded them: no second load, no second wait
+        float dR[3][3];
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v += (dS[a][k] + dS[k][a]) * (g.R[k][b2] * s[b2]);
+                acc += v * g.R[a][b2];
+                dR[a][b2] = v * s[b2];
+            }
+            gs[b2] = acc;
+        }
+        const float r = g.quat[0], qx = g.quat[1], qy = g.quat[2], qz = g.quat[3];
+        gq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
+        gq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - r * dR[1][2] + qz * dR[2][0] + r * dR[2][1] - 2.0f * qx * dR[2][2]);
+        gq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + r * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
+        gq[3] = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
+    }
+    }   // PART != 2
+    return sh_written;
+}
+
 // PART 0: everything in one launch.  The SH degree-3 part needs ~180 VGPRs next to the geometry
 // (2 waves per SIMD: latency-bound), so the staged mode runs as two launches instead:
 // PART 1 = everything but the SH colours (126 VGPRs), PART 2 = the SH part alone, which adds its
@@ -448,14 +722,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const bool in_range = i < N;
     if (!STAGE && !in_range) return;
     const bool drawn = in_range && radii[i] > 0;
-    float gm[3] = {0.f, 0.f, 0.f};
-    float gm2[2] = {0.f, 0.f};
-    float gs[3] = {0.f, 0.f, 0.f};
-    float gq[4] = {0.f, 0.f, 0.f, 0.f};
-    float gc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gop = 0.f;
-    float gcol[3] = {0.f, 0.f, 0.f};
-    constexpr int NB = (DEG + 1) * (DEG + 1);
+    BwdGrads o = {};
+    float (&gm)[3] = o.gm;
+    float (&gm2)[2] = o.gm2;
+    float (&gs)[3] = o.gs;
+    float (&gq)[4] = o.gq;
+    float (&gc6)[6] = o.gc6;
+    float& gop = o.gop;
+    float (&gcol)[3] = o.gcol;
     float* gsh_out = (g_shs && in_range && PART != 1) ? g_shs + (size_t)i * K * 3 : nullptr;
     int sh_written = 0;
     // ---- staged SH rows of this wave's 64 Gaussians
@@ -483,235 +757,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         // The gradient row, the opacity and the side-table row are requested BEFORE the projection is recomputed, so that
         // they travel while it runs (requested after it, the kernel waited for memory three times in a row: radius,
         // geometry, rows).
-        // row = 6 doubles (moments of pv about the box centre) + floats 12..15 (rgb, depth): gsplat_common.h
-        static_assert(GS_GRAD_ROW == 16, "row layout");
-        const float4* row = grad_rows + (GS_GRAD_ROW / 4) * (size_t)i;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 r0 = PART != 2 ? row[0] : z4, r1 = PART != 2 ? row[1] : z4, r2 = PART != 2 ? row[2] : z4, r3 = row[3];
-        const float opacity_i = PART != 2 ? opacities[i] : 0.0f;
-        float4 j0 = z4, j1 = z4, j2 = z4;
-        if (JAC) {
-            const float4* jp = sh_jac + 3 * (size_t)i;
-            j0 = jp[0]; j1 = jp[1]; j2 = jp[2];
-        }
-        Geom g;
-        if (PART != 2) project_gaussian(i, H, W, 0, 1 << 20, view, proj, means3D, scales, rots, cov6, g);
-        const auto dbl = [](float lo, float hi) {
-            return __hiloint2double((int)__float_as_uint(hi), (int)__float_as_uint(lo));
-        };
-        float d_mx = 0.f, d_my = 0.f, d_a = 0.f, d_b = 0.f, d_d = 0.f, d_op = 0.f;
-        const float d_r = r3.x, d_g = r3.y, d_bl = r3.z, d_z = r3.w;
-        if (PART != 2) {
-            // moments of q = opacity * pv about the mean, from the moments of pv about the box centre (double: the
-            // shift can be thousands of pixels for a splat whose mean is far off screen)
-            const double op = (double)opacity_i;
-            const double M0 = dbl(r2.z, r2.w);
-            const double ex = (double)((g.xmin + g.xmax - 1) >> 1) - (double)g.mx;
-            const double ey = (double)((g.ymin + g.ymax - 1) >> 1) - (double)g.my;
-            const double S1x = dbl(r0.x, r0.y), S1y = dbl(r0.z, r0.w);
-            const double Sx = op * (ex * M0 + S1x), Sy = op * (ey * M0 + S1y);
-            const double Sxx = op * (ex * (ex * M0 + 2.0 * S1x) + dbl(r1.x, r1.y));
-            const double Sxy = op * (ex * (ey * M0 + S1y) + ey * S1x + dbl(r1.z, r1.w));
-            const double Syy = op * (ey * (ey * M0 + 2.0 * S1y) + dbl(r2.x, r2.y));
-            // power = -0.5 (a dx^2 + 2 b dx dy + d dy^2), dx = pixel - mean (reference :417-424)
-            d_mx = (float)((double)g.ca * Sx + (double)g.cb * Sy);
-            d_my = (float)((double)g.cd * Sy + (double)g.cb * Sx);
-            d_a = (float)(-0.5 * Sxx);
-            d_b = (float)(-0.5 * Sxy);
-            d_d = (float)(-0.5 * Syy);
-            d_op = (float)M0;
-        }
-        gop = d_op;
-        gm2[0] = d_mx;
-        gm2[1] = d_my;
-        float px, py, pz;            // (the projection has loaded the mean already: a second load here was a second wait)
-        if (PART != 2) { px = g.pos[0]; py = g.pos[1]; pz = g.pos[2]; }
-        else { px = means3D[3 * (size_t)i]; py = means3D[3 * (size_t)i + 1]; pz = means3D[3 * (size_t)i + 2]; }
-        // ---- colour
-        if (colors_precomp) {
-            gcol[0] = d_r; gcol[1] = d_g; gcol[2] = d_bl;
-        } else if (shs && PART != 1) {
-            float b[NB];
-            const float vx = px - campos[0], vy = py - campos[1], vz = pz - campos[2];
-            const float n = sqrtf(vx * vx + vy * vy + vz * vz);
-            const float ne = n + 1e-7f;
-            const float dx = vx / ne, dy = vy / ne, dz = vz / ne;
-            sh_basis<DEG>(dx, dy, dz, b);
-            const float dcol[3] = {d_r, d_g, d_bl};
-            float gcl[3];
-            float ddir[3] = {0.f, 0.f, 0.f};
-            if (JAC) {
-                // W = d colour / d dir and the clamp mask as the forward left them
-                const float Wm[3][3] = {{j0.x, j0.y, j0.z}, {j0.w, j1.x, j1.y}, {j1.z, j1.w, j2.x}};
-                const uint32_t pass = __float_as_uint(j2.y);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    gcl[c] = ((pass >> c) & 1u) ? dcol[c] : 0.0f;
-#pragma unroll
-                    for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
-                }
-            } else {
-            float bg[NB][3];
-            sh_basis_grad<DEG>(dx, dy, dz, bg);
-            // one streaming pass over the coefficients (each loaded value is consumed at once, so the
-            // 48 floats never sit in registers together): colour v[c] = sum_k b_k sh_kc and
-            // Wm[a][c] = sum_k (d b_k / d dir_a) sh_kc; the clamp mask is applied afterwards
-            float vcol[3] = {0.f, 0.f, 0.f};
-            float Wm[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            {
-                const float* p = shs + (size_t)i * K * 3;
-                constexpr int NF = NB * 3;
-                constexpr int NV = (VEC4 && !STAGE) ? (NF + 3) / 4 : 0;
-                const float4* p4 = reinterpret_cast<const float4*>(p);
-                float4 t4[NV > 0 ? NV : 1];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) t4[v] = p4[v];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-#pragma clang fp contract(off)     // the colour must round as in the forward (clamp mask)
-                    float val;
-                    if (STAGE) {
-                        val = st_row[f];
-                    } else if (VEC4) {
-                        const float4 t = t4[f / 4];
-                        val = (f % 4 == 0) ? t.x : (f % 4 == 1) ? t.y : (f % 4 == 2) ? t.z : t.w;
-                    } else {
-                        val = p[f];
-                    }
-                    const int k = f / 3, c = f % 3;
-                    vcol[c] += b[k] * val;
-                    Wm[0][c] += bg[k][0] * val;
-                    Wm[1][c] += bg[k][1] * val;
-                    Wm[2][c] += bg[k][2] * val;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = vcol[c] + 0.5f;
-                gcl[c] = (v >= 0.0f && v <= 1.0f) ? dcol[c] : 0.0f;
-#pragma unroll
-                for (int a2 = 0; a2 < 3; ++a2) ddir[a2] += Wm[a2][c] * gcl[c];
-            }
-            }
-            if (gsh_out && STAGE) {
-#pragma unroll
-                for (int f = 0; f < NB * 3; ++f) st_row[f] = b[f / 3] * gcl[f % 3];
-                sh_written = NB * 3;
-            } else if (gsh_out) {
-                if (VEC4) {   // 16-byte stores: a quarter of the partial-line write requests
-                    constexpr int NV = (NB * 3) / 4;      // whole float4s; the 0..3 floats left go scalar
-                    float4* o4 = reinterpret_cast<float4*>(gsh_out);
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        float t[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = b[(4 * v + e) / 3] * gcl[(4 * v + e) % 3];
-                        if (acc) {
-                            const float4 o = o4[v];
-                            t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
-                        }
-                        o4[v] = make_float4(t[0], t[1], t[2], t[3]);
-                    }
-#pragma unroll
-                    for (int f = 4 * NV; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3] + (acc ? gsh_out[f] : 0.0f);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < NB * 3; ++f) gsh_out[f] = b[f / 3] * gcl[f % 3] + (acc ? gsh_out[f] : 0.0f);
-                }
-                sh_written = NB * 3;
-            }
-            if (n > 0.0f) {
-                const float dot = ddir[0] * vx + ddir[1] * vy + ddir[2] * vz;
-                const float k2 = dot / (ne * ne * n);
-                gm[0] += ddir[0] / ne - vx * k2;
-                gm[1] += ddir[1] / ne - vy * k2;
-                gm[2] += ddir[2] / ne - vz * k2;
-            } else {
-                gm[0] += ddir[0] / ne; gm[1] += ddir[1] / ne; gm[2] += ddir[2] / ne;
-            }
-        }
-        if (PART != 2) {
-        // ---- screen mean
-        {
-            const float wden = g.clip[3] + 1e-7f;
-            const float dnx = 0.5f * (float)W * d_mx, dny = 0.5f * (float)H * d_my;
-            const float dcx = dnx / wden, dcy = dny / wden;
-            const float dcw = -(dnx * g.clip[0] + dny * g.clip[1]) / (wden * wden);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gm[c] += proj[c] * dcx + proj[4 + c] * dcy + proj[12 + c] * dcw;
-        }
-        // ---- conic -> cov2D
-        const float d_inv_det = d_a * g.c11 - 2.0f * d_b * g.c01 + d_d * g.c00;
-        const float d_det = -g.inv_det * g.inv_det * d_inv_det;
-        float G2[2][2];
-        G2[0][0] = d_d * g.inv_det + d_det * g.c11;
-        G2[1][1] = d_a * g.inv_det + d_det * g.c00;
-        G2[0][1] = -d_b * g.inv_det - d_det * g.c01;
-        G2[1][0] = G2[0][1];
-        // ---- cov2D = J Sigma J^T
-        const float J[2][3] = {{g.j00, 0.0f, g.j02}, {0.0f, g.j11, g.j12}};
-        float dS[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) {
-                float v = 0.f;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) v += J[r][a] * G2[r][c] * J[c][b2];
-                dS[a][b2] = v;
-            }
-        float JS[2][3];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                JS[r][c] = J[r][0] * g.S[0][c] + J[r][1] * g.S[1][c] + J[r][2] * g.S[2][c];
-        float dJ[2][3];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                dJ[r][c] = (G2[r][0] + G2[0][r]) * JS[0][c] + (G2[r][1] + G2[1][r]) * JS[1][c];
-        const float focal_x = proj[0] * (float)W / 2.0f, focal_y = proj[5] * (float)H / 2.0f;
-        const float x = g.cam[0], y = g.cam[1], z = g.cam[2];
-        const float zi = z + 1e-7f, z2 = z * z + 1e-7f;
-        float dcam[3];
-        dcam[0] = dJ[0][2] * (-focal_x / z2);
-        dcam[1] = dJ[1][2] * (-focal_y / z2);
-        dcam[2] = dJ[0][0] * (-focal_x / (zi * zi)) + dJ[1][1] * (-focal_y / (zi * zi)) +
-                  dJ[0][2] * (x * focal_x * 2.0f * z / (z2 * z2)) +
-                  dJ[1][2] * (y * focal_y * 2.0f * z / (z2 * z2)) + d_z;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            gm[c] += view[c] * dcam[0] + view[4 + c] * dcam[1] + view[8 + c] * dcam[2];
-        if (cov6) {
-            gc6[0] = dS[0][0]; gc6[1] = dS[0][1] + dS[1][0]; gc6[2] = dS[0][2] + dS[2][0];
-            gc6[3] = dS[1][1]; gc6[4] = dS[1][2] + dS[2][1]; gc6[5] = dS[2][2];
-        } else {
-            const float s[3] = {g.scl[0], g.scl[1], g.scl[2]};     // as the projection loaded them: no second load, no second wait
-            float dR[3][3];
-#pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) {
-                float acc = 0.f;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) v += (dS[a][k] + dS[k][a]) * (g.R[k][b2] * s[b2]);
-                    acc += v * g.R[a][b2];
-                    dR[a][b2] = v * s[b2];
-                }
-                gs[b2] = acc;
-            }
-            const float r = g.quat[0], qx = g.quat[1], qy = g.quat[2], qz = g.quat[3];
-            gq[0] = 2.0f * (-qz * dR[0][1] + qy * dR[0][2] + qz * dR[1][0] - qx * dR[1][2] - qy * dR[2][0] + qx * dR[2][1]);
-            gq[1] = 2.0f * (qy * dR[0][1] + qz * dR[0][2] + qy * dR[1][0] - 2.0f * qx * dR[1][1] - r * dR[1][2] + qz * dR[2][0] + r * dR[2][1] - 2.0f * qx * dR[2][2]);
-            gq[2] = 2.0f * (-2.0f * qy * dR[0][0] + qx * dR[0][1] + r * dR[0][2] + qx * dR[1][0] + qz * dR[1][2] - r * dR[2][0] + qz * dR[2][1] - 2.0f * qy * dR[2][2]);
-            gq[3] = 2.0f * (-2.0f * qz * dR[0][0] - r * dR[0][1] + qx * dR[0][2] + r * dR[1][0] - 2.0f * qz * dR[1][1] + qy * dR[1][2] + qx * dR[2][0] + qy * dR[2][1]);
-        }
-        }   // PART != 2
+        const BwdInputs in = bwd_request<PART, JAC>(i, opacities, grad_rows, sh_jac);
+        sh_written = bwd_one_view<DEG, MODE, PART, JAC, false>(in, i, K, H, W, view, proj, campos, means3D, scales, rots, cov6, shs,
+                                                               colors_precomp, st_row, gsh_out, acc, o);
     }
     if (PART == 2) {
         if (drawn && g_means3D) {   // add the SH part's share to what PART 1 wrote
@@ -783,6 +831,110 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             for (; k + 4 <= K * 3; k += 4) o4[k >> 2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (; k < K * 3; ++k) gsh_out[k] = 0.0f;
+    }
+}
+
+// k views of the SAME Gaussians in one launch (the training step of SURVEY.md 8e / config 4: a rank renders several views
+// per step and only the sum of their gradients is wanted).  The side-table staged form only (shs with 3 K <= 48 floats,
+// every view's sh_jac): a lane keeps the sum of the views' geometry gradients in registers and of the SH rows in its LDS
+// row, and every output row is written ONCE -- the view-by-view form (gs_preprocess_bwd with `accumulate`) reads and
+// rewrites all 59 floats per Gaussian and view.  The sums are taken in view order, like the view-by-view form takes them.
+struct BwdView {
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const int32_t* radii;
+    const float4* rows;
+    const float4* sh_jac;
+    float* g_means2D;
+    int H, W;
+};
+struct BwdViews {
+    BwdView v[GS_MAX_BWD_VIEWS];
+};
+
+template <int DEG>
+__global__ __launch_bounds__(256) void preprocess_bwd_views_kernel(
+    int N, int K, int nv, const BwdViews views, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rots, const float* __restrict__ cov6, const float* __restrict__ opacities,
+    const float* __restrict__ shs, float* __restrict__ g_means3D, float* __restrict__ g_scales,
+    float* __restrict__ g_rots, float* __restrict__ g_cov6, float* __restrict__ g_opac, float* __restrict__ g_shs,
+    bool acc) {
+    __shared__ float stage_all[4 * 64 * BWD_STAGE_STRIDE];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = i < N;
+    const int lane = threadIdx.x & 63;
+    float* st_wave = stage_all + (threadIdx.x >> 6) * 64 * BWD_STAGE_STRIDE;
+    float* st_row = st_wave + lane * BWD_STAGE_STRIDE;
+    const int RL = 3 * K;
+    const int i0 = i - lane;
+    const int nq = i0 < N ? ((N - i0 < 64 ? N - i0 : 64) * RL) / 4 : 0;
+    if (g_shs)
+        for (int f = 0; f < RL; ++f) st_row[f] = 0.0f;
+    BwdGrads tot = {};
+    bool any = false;
+    for (int v = 0; v < nv; ++v) {
+        const BwdView& vw = views.v[v];
+        const bool drawn = in_range && vw.radii[i] > 0;
+        BwdGrads o = {};
+        if (drawn) {
+            const BwdInputs in = bwd_request<0, true>(i, opacities, vw.rows, vw.sh_jac);
+            bwd_one_view<DEG, 2, 0, true, true>(in, i, K, vw.H, vw.W, vw.view, vw.proj, vw.campos, means3D, scales, rots, cov6,
+                                                shs, nullptr, st_row, g_shs ? st_row : nullptr, false, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { tot.gm[c] += o.gm[c]; tot.gs[c] += o.gs[c]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tot.gq[c] += o.gq[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) tot.gc6[c] += o.gc6[c];
+            tot.gop += o.gop;
+            any = true;
+        }
+        if (in_range && vw.g_means2D) {
+            vw.g_means2D[3 * (size_t)i] = o.gm2[0] * 0.5f * (float)vw.W;
+            vw.g_means2D[3 * (size_t)i + 1] = o.gm2[1] * 0.5f * (float)vw.H;
+            vw.g_means2D[3 * (size_t)i + 2] = 0.0f;
+        }
+    }
+    if (in_range && (any || !acc)) {       // acc: rows of Gaussians no view draws stay as they are
+        if (g_means3D) {
+            float* q = g_means3D + 3 * (size_t)i;
+            const float o0 = acc ? q[0] : 0.f, o1 = acc ? q[1] : 0.f, o2 = acc ? q[2] : 0.f;
+            q[0] = o0 + tot.gm[0]; q[1] = o1 + tot.gm[1]; q[2] = o2 + tot.gm[2];
+        }
+        if (g_scales) {
+            float* q = g_scales + 3 * (size_t)i;
+            const float o0 = acc ? q[0] : 0.f, o1 = acc ? q[1] : 0.f, o2 = acc ? q[2] : 0.f;
+            q[0] = o0 + tot.gs[0]; q[1] = o1 + tot.gs[1]; q[2] = o2 + tot.gs[2];
+        }
+        if (g_rots) {
+            float4* q = reinterpret_cast<float4*>(g_rots + 4 * (size_t)i);
+            const float4 t = acc ? *q : make_float4(0.f, 0.f, 0.f, 0.f);
+            *q = make_float4(t.x + tot.gq[0], t.y + tot.gq[1], t.z + tot.gq[2], t.w + tot.gq[3]);
+        }
+        if (g_cov6) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g_cov6[6 * (size_t)i + k] = (acc ? g_cov6[6 * (size_t)i + k] : 0.f) + tot.gc6[k];
+        }
+        if (g_opac) g_opac[i] = (acc ? g_opac[i] : 0.f) + tot.gop;
+    }
+    if (g_shs) {   // kernel-uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4* q4 = reinterpret_cast<float4*>(g_shs + (size_t)i0 * RL);
+        const uint64_t dmask = __ballot(any);
+        for (int m = lane; m < nq; m += 64) {
+            const unsigned f = 4u * (unsigned)m, gi = f / (unsigned)RL, off = f - gi * (unsigned)RL;
+            const float* d = st_wave + gi * BWD_STAGE_STRIDE + off;
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v o = {d[0], d[1], d[2], d[3]};
+            if (acc) {
+                if (!((dmask >> gi) & 1ull)) continue;
+                const float4 t = q4[m];
+                o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(q4) + m);
+        }
     }
 }
 
@@ -907,4 +1059,60 @@ extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, cons
         case 2: return launch_bwd<2>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, (const float4*)sh_jac, stream);
         default: return launch_bwd<3>(mode, N, K, H, W, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, radii, rows, g_means3D, g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, g_colors, accumulate != 0, (const float4*)sh_jac, stream);
     }
+}
+
+extern "C" int gs_preprocess_bwd_views(int n_views, const GsBwdView* views, int N, int K, int sh_degree,
+                                       const float* means3D, const float* scales, const float* rotations,
+                                       const float* cov3D_precomp, const float* opacities, const float* shs,
+                                       const float* colors_precomp, float* g_means3D, float* g_scales,
+                                       float* g_rotations, float* g_cov3D, float* g_opacities, float* g_shs,
+                                       float* g_colors, int accumulate, void* stream_) {
+    GS_REQUIRE(n_views >= 0 && (n_views == 0 || views), "n_views = %d with views = %p", n_views, (const void*)views);
+    if (N == 0 || n_views == 0) return GS_OK;
+    const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0) && (((uintptr_t)g_shs & 15) == 0);
+    bool fused = vec4 && K * 3 <= BWD_STAGE_MAX_ROW && n_views > 1;
+    for (int v = 0; v < n_views; ++v) fused = fused && views[v].sh_jac != nullptr;
+    if (!fused) {     // the same sums view by view
+        for (int v = 0; v < n_views; ++v) {
+            const GsBwdView& w = views[v];
+            const int rc = gs_preprocess_bwd(N, K, sh_degree, w.H, w.W, w.viewmatrix, w.projmatrix, w.campos, means3D, scales,
+                                             rotations, cov3D_precomp, opacities, shs, colors_precomp, w.radii, w.grad_rows,
+                                             g_means3D, w.g_means2D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs,
+                                             g_colors, (accumulate != 0 || v > 0) ? 1 : 0, w.sh_jac, stream_);
+            if (rc) return rc;
+        }
+        return GS_OK;
+    }
+    GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
+    GS_REQUIRE(!g_rotations || ((uintptr_t)g_rotations & 15) == 0, "g_rotations must be 16-byte aligned");
+    GS_REQUIRE(opacities, "null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid(gs_div_up(N, 256)), block(256);
+    for (int v0 = 0; v0 < n_views; v0 += GS_MAX_BWD_VIEWS) {
+        const int nv = n_views - v0 < GS_MAX_BWD_VIEWS ? n_views - v0 : GS_MAX_BWD_VIEWS;
+        BwdViews a = {};
+        for (int v = 0; v < nv; ++v) {
+            const GsBwdView& w = views[v0 + v];
+            const int rc = check_common(N, K, sh_degree, w.H, w.W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
+            if (rc) return rc;
+            GS_REQUIRE(w.viewmatrix && w.projmatrix && w.campos && w.radii && w.grad_rows, "view %d: null argument", v0 + v);
+            GS_REQUIRE(((uintptr_t)w.grad_rows & 15) == 0 && ((uintptr_t)w.sh_jac & 15) == 0,
+                       "view %d: grad_rows and sh_jac must be 16-byte aligned", v0 + v);
+            a.v[v] = BwdView{w.viewmatrix, w.projmatrix, w.campos, w.radii, (const float4*)w.grad_rows,
+                             (const float4*)w.sh_jac, w.g_means2D, w.H, w.W};
+        }
+        const bool acc = accumulate != 0 || v0 > 0;
+#define GS_LAUNCH_BWD_VIEWS(D_)                                                                                          \
+    hipLaunchKernelGGL((preprocess_bwd_views_kernel<D_>), grid, block, 0, stream, N, K, nv, a, means3D, scales, rotations, \
+                       cov3D_precomp, opacities, shs, g_means3D, g_scales, g_rotations, g_cov3D, g_opacities, g_shs, acc)
+        switch (sh_degree) {
+            case 0: GS_LAUNCH_BWD_VIEWS(0); break;
+            case 1: GS_LAUNCH_BWD_VIEWS(1); break;
+            case 2: GS_LAUNCH_BWD_VIEWS(2); break;
+            default: GS_LAUNCH_BWD_VIEWS(3); break;
+        }
+#undef GS_LAUNCH_BWD_VIEWS
+        GS_CHECK_LAUNCH("preprocess_bwd_views");
+    }
+    return GS_OK;
 }

@@ -288,23 +288,28 @@ class _RasterizeSharded(torch.autograd.Function):
             rows_mine = rows_mine.view(world, n, R.grad_row_floats())
             # 5. chain rule through my shard's projection into each view, summed over the views.  My own view's rows
             # never travel: its launch reads them where render_backward left them and runs while the all-to-all is
-            # in flight; it writes, the others add in place (accumulate flag of the C-ABI).
+            # in flight; the other world - 1 views then take ONE launch that adds their sum to it in place
+            # (gs_preprocess_bwd_views with the accumulate flag: one read-modify-write of the gradients, not world - 1).
             off = int(sum(counts[:rank]))
-            acc = None
-            g_m2d = {}
-            for v in [rank] + [u for u in range(world) if u != rank]:
-                if v != rank and w_rows is not None:
-                    with _stage("exchange_bwd_wait"):
-                        _wait(w_rows)
-                    w_rows = None
-                g = R.preprocess_backward(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                          colors_precomp, radii[v], rows[off:off + n] if v == rank else rows_mine[v], needs,
-                                          (n, 3) if per_view_means2D else None, accumulate_into=acc,
-                                          sh_jac=None if sh_jac is None else sh_jac[v])
-                if per_view_means2D and needs[1]:
-                    g_m2d[v] = g[1]
-                acc = g
-            _wait(w_rows)        # world 1: nothing waited above
+            m2d_shape = (n, 3) if per_view_means2D else None
+            acc = R.preprocess_backward(views[rank], means3D, opacities, scales, rotations, cov3D_precomp, shs,
+                                        colors_precomp, radii[rank], rows[off:off + n], needs, m2d_shape,
+                                        sh_jac=None if sh_jac is None else sh_jac[rank])
+            g_m2d = {rank: acc[1]} if (per_view_means2D and needs[1]) else {}
+            with _stage("exchange_bwd_wait"):
+                _wait(w_rows)
+            others = [u for u in range(world) if u != rank]
+            if others:
+                needs_o = list(needs)
+                needs_o[1] = bool(per_view_means2D and needs[1])
+                g = R.preprocess_backward_views([views[u] for u in others], means3D, opacities, scales, rotations,
+                                                cov3D_precomp, shs, colors_precomp, [radii[u] for u in others],
+                                                [rows_mine[u] for u in others], needs_o,
+                                                sh_jacs=None if sh_jac is None else [sh_jac[u] for u in others],
+                                                accumulate_into=acc)
+                if needs_o[1]:
+                    for j, u in enumerate(others):
+                        g_m2d[u] = g[1][j]
             g_m2d = [g_m2d[v] for v in range(world)] if g_m2d else []
             acc = list(acc)
             if needs[1] and ctx.means2D_shape is not None:
@@ -403,9 +408,10 @@ def bucket_ranges(n: int, num_buckets: int, align: int = 256):
 
 class _RasterizeViews(torch.autograd.Function):
     """k camera views of the same (replicated) Gaussians as ONE autograd node: the forward renders every view; the
-    backward adds the views' gradients up in place -- gs_preprocess_bwd's `accumulate` flag, no per-view gradient
-    tensors -- and, for the LAST view, runs gs_preprocess_bwd per Gaussian range and all-reduces each range's
-    gradients as soon as its launch is queued (see ViewShardedStep).  Outputs: k images, k radii, k depths, k alphas."""
+    backward runs every view's tile backward, then the chain rule of ALL k views as one launch per Gaussian range
+    (gs_preprocess_bwd_views: the views' sums never leave registers / LDS, no per-view gradient tensors, every gradient
+    row written once) and all-reduces each range's gradients as soon as its launch is queued (see ViewShardedStep).
+    Outputs: k images, k radii, k depths, k alphas."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
@@ -478,14 +484,17 @@ class _RasterizeViews(torch.autograd.Function):
             reduce_now = owner.world > 1 or owner.force_collectives
             works = []
             # lean launches: the camera tensors are converted once per view and the C-ABI is called on base pointers + row
-            # offsets (per range the host must queue 2 kernels and one grouped all-reduce faster than the GPU finishes
+            # offsets (per range the host must queue one kernel and one grouped all-reduce faster than the GPU finishes
             # them, or the overlap is lost to launch gaps)
             lib = R._lib.load()
             K = shs.shape[1] if shs is not None else 0
             st = R._stream()
 
+            def addr(t, b):                    # address of row b (every per-Gaussian tensor here has 4-byte elements)
+                return None if t is None else t.data_ptr() + b * t.stride(0) * 4
+
             def at(t, b):
-                return None if t is None else R.C.c_void_p(t.data_ptr() + b * t.stride(0) * 4)
+                return None if t is None else R.C.c_void_p(addr(t, b))
 
             g_m3, _, g_sh, g_col, g_op, g_sc, g_rot, g_cov = full
             live = [v for v in range(k) if not (g_images[v] is None and g_depths[v] is None and g_alphas[v] is None)]
@@ -495,34 +504,44 @@ class _RasterizeViews(torch.autograd.Function):
                         t.zero_()
             elif m2d_views is not None and len(live) < k:
                 m2d_views.zero_()
-            written = False
-            for v in live:
+            # 1. every view's tile backward: ten sums per (Gaussian, view) in that view's own 64-byte rows
+            descs = (R._lib.GsBwdView * max(len(live), 1))()
+            keep = []                          # camera tensors stay alive until the launches are queued
+            for j, v in enumerate(live):
                 settings = ctx.views[v]
                 splat, radii, point_list, ranges, depth, alpha, aux, jac = per_view[v]
                 rows, ctx.rows[v] = ctx.rows[v], None          # cleared by the forward; a second backward clears its own
                 rows = R.render_backward(settings, splat, ranges, point_list, aux, depth, alpha, g_images[v], g_depths[v],
                                          g_alphas[v], rows, ctx.t_eps, ctx.bands[v])
-                cam_p = [R._ptr(R._camera_tensor(getattr(settings, name), n, name, dev)) for name, n in
-                         (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
-                H, W = settings.image_height, settings.image_width
+                cams = [R._camera_tensor(getattr(settings, name), n, name, dev) for name, n in
+                        (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
                 g_m2 = m2d_views[v] if m2d_views is not None else None
                 jac = jac if shs is not None else None     # (N, 12): a range is a row slice like everything else
-                last = v == live[-1]
-                # every view but the last: one launch over all N; the last: per range, each followed by its all-reduce
-                spans = bucket_ranges(N, owner.num_buckets) if (last and reduce_now) else ([(0, N)] if N else [])
-                for (b, e) in spans:
-                    with _stage("preprocess_bwd"):
-                        R._lib.check(lib.gs_preprocess_bwd(
-                            e - b, K, settings.sh_degree, H, W, *cam_p, at(means3D, b), at(scales, b), at(rotations, b),
-                            at(cov3D_precomp, b), at(opacities, b), at(shs, b), at(colors_precomp, b), at(radii, b),
-                            at(rows, b), at(g_m3, b), at(g_m2, b), at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b),
-                            at(g_sh, b), at(g_col, b), 1 if written else 0, at(jac, b), st),
-                            "gs_preprocess_bwd")
-                    if last and reduce_now:   # queued behind this range's launches on RCCL's stream; the next range's kernels overlap it
-                        with _stage("allreduce_launch"):
-                            works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
-                                                         owner.group, async_op=True))
-                written = True
+                keep.append((cams, rows, radii, jac, g_m2))
+                d = descs[j]
+                d.viewmatrix, d.projmatrix, d.campos = (t.data_ptr() for t in cams)
+                d.H, d.W = settings.image_height, settings.image_width
+            # 2. the chain rule per Gaussian range, ALL local views in one launch (gs_preprocess_bwd_views: the views' sums
+            #    stay in registers / LDS and every gradient row is written once), each range followed by its all-reduce
+            spans = bucket_ranges(N, owner.num_buckets) if reduce_now else ([(0, N)] if N else [])
+            sh_degree = ctx.views[0].sh_degree
+            for (b, e) in (spans if live else []):
+                for j in range(len(live)):
+                    _, rows, radii, jac, g_m2 = keep[j]
+                    d = descs[j]
+                    d.radii, d.grad_rows = addr(radii, b), addr(rows, b)
+                    d.sh_jac, d.g_means2D = addr(jac, b), addr(g_m2, b)
+                with _stage("preprocess_bwd"):
+                    R._lib.check(lib.gs_preprocess_bwd_views(
+                        len(live), descs, e - b, K, sh_degree, at(means3D, b), at(scales, b), at(rotations, b),
+                        at(cov3D_precomp, b), at(opacities, b), at(shs, b), at(colors_precomp, b), at(g_m3, b),
+                        at(g_sc, b), at(g_rot, b), at(g_cov, b), at(g_op, b), at(g_sh, b), at(g_col, b), 0, st),
+                        "gs_preprocess_bwd_views")
+                if reduce_now:   # queued behind this range's launch on RCCL's stream; the next range's kernel overlaps it
+                    with _stage("allreduce_launch"):
+                        works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
+                                                     owner.group, async_op=True))
+            del keep
             if not live and reduce_now:       # keep the collective sequence identical on every rank
                 for (b, e) in bucket_ranges(N, owner.num_buckets):
                     works.append(_all_reduce_sum([t[b:e] for i, t in enumerate(full) if t is not None and i != 1],
@@ -544,12 +563,13 @@ class ViewShardedStep:
     per Gaussian at SH degree 3).  No counterpart in the reference (one view per iteration on one device,
     train.py:129-135); equal to sequential accumulation of the same views on one device up to fp32 summation order.
 
-    The backward adds the local views up in place (gs_preprocess_bwd's `accumulate` flag: views 1..k-1 of the rank cost
-    no gradient tensors of their own and no collective); the LAST local view runs gs_preprocess_bwd once per Gaussian
-    range -- the C-ABI takes base pointers and a count, so a range is a row slice of every per-Gaussian tensor -- and
-    launches that range's all-reduce (one grouped RCCL call over its slices of the gradient tensors) right after its
-    kernels are queued: RCCL's stream starts on range b while this stream computes range b + 1, and only the last
-    range's transfer is exposed.  One exchange per step, whatever the number of local views: the wire time is amortised
+    The backward first runs the tile backward of every local view (each into its own 64-byte gradient rows), then the
+    per-Gaussian chain rule of ALL local views at once, one gs_preprocess_bwd_views launch per Gaussian range -- the views'
+    sums are formed in registers / LDS in view order and every gradient row is written once (views 1..k-1 of the rank cost
+    no gradient tensors, no read-modify-write pass and no collective); the C-ABI takes base pointers and a count, so a
+    range is a row slice of every per-Gaussian tensor -- and launches that range's all-reduce (one grouped RCCL call over
+    its slices of the gradient tensors) right after its kernel is queued: RCCL's stream starts on range b while this
+    stream computes range b + 1, and only the last range's transfer is exposed.  One exchange per step, whatever the number of local views: the wire time is amortised
     over 8 / world views.  The gradients autograd hands to the parameters are already summed over views and ranks
     (divided by the world size if `average`).  means2D (optional, (k, N, 3)): its gradient is the per-view screen-space
     gradient (the densification statistic); it and radii (k of them) are not exchanged -- fold them into the per-Gaussian
@@ -566,6 +586,8 @@ class ViewShardedStep:
         self.views = list(views)
         if not self.views:
             raise ValueError("ViewShardedStep needs at least one view per rank (give every rank a view, or a smaller world)")
+        if len({int(rs.sh_degree) for rs in self.views}) > 1:
+            raise ValueError("the views of one step must share sh_degree (one model, one active degree)")
         self.t_eps = DEFAULT_T_EPS if t_eps is None else t_eps
         self.num_buckets = int(num_buckets)
         self.average = average

@@ -456,6 +456,54 @@ def preprocess_backward(settings, means3D, opacities, scales, rotations, cov3D_p
     return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov
 
 
+def preprocess_backward_views(views, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp, radii,
+                              rows, needs, sh_jacs=None, accumulate_into=None):
+    """gs_preprocess_bwd_views on the current stream: the chain rule of k views of the same Gaussians, summed over the
+    views in view order, every gradient row written once.  views = k settings; radii, rows, sh_jacs = k tensors each (what
+    each view's forward / tile backward left).  Returns the 8 gradients in the order of GaussianRasterizer.forward's
+    arguments; means2D's is (k, N, 3), one slab per view (a per-view statistic, never summed).  accumulate_into = the
+    8-tuple an earlier call returned: the sums are added into those tensors."""
+    lib = _lib.load()
+    dev = means3D.device
+    N, k = means3D.shape[0], len(views)
+    K = shs.shape[1] if shs is not None else 0
+    if len({int(st.sh_degree) for st in views}) > 1:
+        raise ValueError("the views of one call must share sh_degree")
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_means2D = torch.empty((k, N, 3), **f32) if needs[1] else None
+    if accumulate_into is not None:
+        g_means3D, _, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov = accumulate_into
+    else:
+        g_means3D = torch.empty((N, 3), **f32) if needs[0] else None
+        g_shs = torch.empty_like(shs) if (shs is not None and needs[2]) else None
+        g_colors = torch.empty((N, 3), **f32) if (colors_precomp is not None and needs[3]) else None
+        g_opac = torch.empty((N, 1), **f32) if needs[4] else None
+        g_scales = torch.empty((N, 3), **f32) if (scales is not None and needs[5]) else None
+        g_rots = torch.empty((N, 4), **f32) if (rotations is not None and needs[6]) else None
+        g_cov = torch.empty((N, 6), **f32) if (cov3D_precomp is not None and needs[7]) else None
+    descs = (_lib.GsBwdView * max(k, 1))()
+    keep = []
+    for j, st in enumerate(views):
+        cams = [_camera_tensor(getattr(st, name), n, name, dev) for name, n in
+                (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
+        keep.append(cams)
+        d = descs[j]
+        d.viewmatrix, d.projmatrix, d.campos = (t.data_ptr() for t in cams)
+        d.radii, d.grad_rows = radii[j].data_ptr(), rows[j].data_ptr()
+        jac = sh_jacs[j] if (sh_jacs is not None and shs is not None) else None
+        d.sh_jac = _jac_ptr(jac, N).value if jac is not None else None
+        d.g_means2D = g_means2D[j].data_ptr() if g_means2D is not None else None
+        d.H, d.W = st.image_height, st.image_width
+    with _stage("preprocess_bwd"):
+        _lib.check(lib.gs_preprocess_bwd_views(k, descs, N, K, views[0].sh_degree if k else 0, _ptr(means3D), _ptr(scales),
+                                               _ptr(rotations), _ptr(cov3D_precomp), _ptr(opacities), _ptr(shs),
+                                               _ptr(colors_precomp), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rots),
+                                               _ptr(g_cov), _ptr(g_opac), _ptr(g_shs), _ptr(g_colors),
+                                               0 if accumulate_into is None else 1, _stream()),
+                   "gs_preprocess_bwd_views")
+    return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,

@@ -42,8 +42,8 @@ extern "C" {
  * gradient rows, sh_jac rows) or a precondition changes: a binding compares gs_version() with the GS_ABI_VERSION it was
  * written against before its first call (gaussian-splatting_amd/_lib.py does) -- a mismatch means shifted arguments.
  * 100: round 1.  200: round 2 (sh_jac arguments, 64-byte gradient rows with six doubles, gs_identify_tile_ranges writes the
- * whole table and wants 16-byte aligned keys).  300: this header. */
-#define GS_ABI_VERSION 300
+ * whole table and wants 16-byte aligned keys).  300: round 3.  301: this header (gs_preprocess_bwd_views added). */
+#define GS_ABI_VERSION 301
 int gs_version(void);            /* == GS_ABI_VERSION of the header the library was built from */
 const char* gs_last_error(void); /* message of this thread's last failing call */
 const char* gs_source_sha(void); /* hash of the sources this library was compiled from (csrc/source_sha.py), "unknown" outside the Makefile */
@@ -208,6 +208,35 @@ int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* vi
                       const float* grad_rows, float* g_means3D, float* g_means2D, float* g_scales,
                       float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
                       float* g_colors_precomp, int accumulate, const float* sh_jac, void* stream);
+
+/*
+ * gs_preprocess_bwd for k views of the SAME Gaussians, summed: equal to gs_preprocess_bwd(view 0, accumulate) followed by
+ * gs_preprocess_bwd(view v, accumulate = 1) for v = 1..k-1 -- the sums are taken in that order -- with every output row
+ * written once.  No counterpart in the reference (one view per iteration, train.py:129-135); it is the backward of the
+ * multi-view training step of SURVEY.md 8e (config 4: 8 views per step, parallel.ViewShardedStep), where the view-by-view
+ * form reads and rewrites 59 floats per Gaussian and view.
+ * views: HOST array of n_views descriptors (device pointers inside; read during the call, not kept).  Per view: the
+ * camera, the radii and the sh_jac table its gs_preprocess_fwd wrote, the grad_rows its gs_render_bwd wrote, and
+ * g_means2D (may be NULL), that view's own (N,3) densification statistic.  Everything else as gs_preprocess_bwd.
+ * One launch per GS_MAX_BWD_VIEWS views when shs is given with rows of at most 48 floats (16-byte aligned) and every view
+ * has its sh_jac; any other combination of inputs runs the view-by-view form inside the call (same results).
+ */
+#define GS_MAX_BWD_VIEWS 8
+typedef struct GsBwdView {
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    const int32_t* radii;
+    const float* grad_rows;
+    const float* sh_jac;
+    float* g_means2D;
+    int32_t H, W;
+} GsBwdView;
+int gs_preprocess_bwd_views(int n_views, const GsBwdView* views, int N, int K, int sh_degree, const float* means3D,
+                            const float* scales, const float* rotations, const float* cov3D_precomp,
+                            const float* opacities, const float* shs, const float* colors_precomp, float* g_means3D,
+                            float* g_scales, float* g_rotations, float* g_cov3D_precomp, float* g_opacities, float* g_shs,
+                            float* g_colors_precomp, int accumulate, void* stream);
 
 /*
  * Training loss, fused (the step right after the rasterizer in every iteration).

@@ -698,3 +698,87 @@ def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
             assert (acc[k] - want).abs().max().item() <= 1e-6 * want.abs().max().item(), name
         else:
             assert torch.equal(acc[k], want), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,k", [("sh_deg3_jac", 3), ("sh_deg1_jac", 2), ("sh_deg3_jac", 11), ("sh_deg3_no_jac", 3),
+                                       ("colors_cov3d", 3), ("sh_deg3_K20_vec4", 2), ("sh_deg3_jac", 1)])
+def test_preprocess_bwd_views_equals_view_by_view_accumulation(dgr, variant, k):
+    """gs_preprocess_bwd_views (k views of the same Gaussians in one launch, the backward of the multi-view step) against
+    gs_preprocess_bwd called view by view with `accumulate`: the same sums in the same order, so the results agree to
+    fp32 rounding of single operations (1e-6 of the largest entry; the fused kernel may contract b*g + sum into one fma),
+    each view's means2D statistic bit for bit.  k = 11 takes two launches (GS_MAX_BWD_VIEWS = 8), the second
+    accumulating; *_no_jac, colors_cov3d and K20 rows take the view-by-view form inside the call: bit-identical.
+    Then once more with accumulate_into (the sums added to an earlier call's)."""
+    R = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    dev = torch.device("cuda:0")
+    N, H, W = 5000, 120, 168
+    K, deg = {"sh_deg3_jac": (16, 3), "sh_deg1_jac": (4, 1), "sh_deg3_no_jac": (16, 3), "colors_cov3d": (1, 0),
+              "sh_deg3_K20_vec4": (20, 3)}[variant]
+    use_jac = variant.endswith("_jac") and not variant.endswith("_no_jac")
+    fused = use_jac and k > 1
+    sc = syn.make_scene(N, K, H, W, seed=12, sh_degree=deg)
+    m3, sh, op, s, q = (getattr(sc, n).to(dev) for n in ("means3D", "shs", "opacities", "scales", "rotations"))
+    colors = cov6 = None
+    if variant == "colors_cov3d":
+        g = torch.Generator().manual_seed(1)
+        colors = torch.rand(N, 3, generator=g).to(dev)
+        Rm = torch.randn(N, 3, 3, generator=g) * 0.05
+        S = Rm @ Rm.transpose(1, 2) + 1e-4 * torch.eye(3)
+        cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous().to(dev)
+        sh = s = q = None
+    settings = [_scene_settings(dgr, syn.jitter_view(sc, 3 * j), dev) for j in range(k)]
+    gr = torch.Generator().manual_seed(3)
+    rows = [torch.cat([torch.randn(N, 6, generator=gr, dtype=torch.float64).view(torch.float32),
+                       torch.randn(N, 4, generator=gr)], dim=1).contiguous().to(dev) for _ in range(k)]
+    needs = [True] * 8
+    radii, jacs = [], []
+    for st in settings:
+        jac = torch.full((N, R.sh_jac_row_floats()), float("nan"), device=dev) if use_jac else None
+        _, r, *_ = R.preprocess(st, m3, op, s, q, cov6, sh, colors, sh_jac=jac)
+        radii.append(r)
+        jacs.append(jac)
+    if k > 1:
+        drawn = torch.stack([r > 0 for r in radii])
+        assert int((drawn.any(0) & ~drawn.all(0)).sum()) > 0        # some Gaussians are drawn in some views only
+        assert int((~drawn.any(0)).sum()) > 0                        # and some in none
+    want, m2d = None, []
+    for st, r, rw, jac in zip(settings, radii, rows, jacs):
+        want = R.preprocess_backward(st, m3, op, s, q, cov6, sh, colors, r, rw, needs, (N, 3), accumulate_into=want, sh_jac=jac)
+        m2d.append(want[1])
+    got = R.preprocess_backward_views(settings, m3, op, s, q, cov6, sh, colors, radii, rows, needs, sh_jacs=jacs if use_jac else None)
+    torch.cuda.synchronize()
+    names = ("means3D", "means2D", "shs", "colors", "opacities", "scales", "rotations", "cov3D")
+
+    def compare(got, want, scale=1.0):
+        for j, name in enumerate(names):
+            if name == "means2D":
+                assert tuple(got[j].shape) == (k, N, 3)
+                for v in range(k):
+                    assert torch.equal(got[j][v], m2d[v]), (name, v)
+                continue
+            if want[j] is None:
+                assert got[j] is None, name
+                continue
+            assert torch.isfinite(got[j]).all(), name
+            if fused:
+                assert (got[j] - want[j]).abs().max().item() <= 1e-6 * scale * want[j].abs().max().item(), name
+            else:
+                assert torch.equal(got[j], want[j]), name
+
+    compare(got, want)
+    # accumulate_into: the same sums added to what an earlier call left
+    first = [None if t is None else t.clone() for t in got]
+    again = R.preprocess_backward_views(settings, m3, op, s, q, cov6, sh, colors, radii, rows, needs,
+                                        sh_jacs=jacs if use_jac else None, accumulate_into=got)
+    torch.cuda.synchronize()
+    twice = [None if t is None else 2.0 * t for t in first]
+    for j, name in enumerate(names):
+        if name == "means2D" or first[j] is None:
+            continue
+        assert again[j].data_ptr() == got[j].data_ptr(), name
+        lim = 2e-6 * first[j].abs().max().item()
+        assert (again[j] - twice[j]).abs().max().item() <= lim, name
+    for v in range(k):
+        assert torch.equal(again[1][v], m2d[v])

@@ -34,6 +34,13 @@ class GsBwdView(C.Structure):
                 ("sh_jac", _vp), ("g_means2D", _vp), ("H", C.c_int32), ("W", C.c_int32)]
 
 
+class GsFwdView(C.Structure):
+    """struct GsFwdView of include/gsplat.h (one view of gs_preprocess_fwd_views)"""
+    _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("splat", _vp), ("radii", _vp),
+                ("tiles_touched", _vp), ("depth_keys", _vp), ("ids", _vp), ("rects", _vp), ("sh_jac", _vp),
+                ("H", C.c_int32), ("W", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32)]
+
+
 MAX_BWD_VIEWS = 8      # GS_MAX_BWD_VIEWS: views per launch of gs_preprocess_bwd_views (more are taken in chunks)
 
 # name -> (restype, argtypes); mirrors include/gsplat.h one to one
@@ -46,6 +53,7 @@ PROTOTYPES = {
     "gs_sh_jac_row_floats": (_i, []),
     "gs_preprocess_fwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 16 + [_i, _i, _vp, _vp]),
     "gs_preprocess_bwd": (_i, [_i, _i, _i, _i, _i] + [_vp] * 20 + [_i, _vp, _vp]),
+    "gs_preprocess_fwd_views": (_i, [_i, C.POINTER(GsFwdView), _i, _i, _i] + [_vp] * 7 + [_vp]),
     "gs_preprocess_bwd_views": (_i, [_i, C.POINTER(GsBwdView), _i, _i, _i] + [_vp] * 14 + [_i, _vp]),
     "gs_scan_workspace_bytes": (_sz, [_ll]),
     "gs_scan_tiles": (_i, [_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -69,7 +77,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 301     # GS_ABI_VERSION of the include/gsplat.h these prototypes were written against
+ABI_VERSION = 302     # GS_ABI_VERSION of the include/gsplat.h these prototypes were written against
 
 
 def load():

@@ -304,24 +304,18 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int i, in
 // colour gradient.  Written by the forward in the order the backward's own pass would have summed it.
 static_assert(GS_SH_JAC_ROW == 12, "nine Jacobian entries + the clamp mask, padded to three float4");
 
+// One view of one Gaussian: everything preprocess_fwd_kernel does, shared with the multi-view kernel below.
+// sh_h / opacity_i / requested: the coefficients and the opacity of this Gaussian and whether they have been requested
+// already (a multi-view caller keeps them across its views: they are read once).  st: this wave's 3 KB of LDS.
 template <int DEG, bool VEC4, bool JAC>
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
-    int N, int K, int H, int W, int row_b, int row_e, const float* __restrict__ view, const float* __restrict__ proj,
-    const float* __restrict__ campos, const float* __restrict__ means3D,
-    const float* __restrict__ scales, const float* __restrict__ rots,
-    const float* __restrict__ cov6, const float* __restrict__ opacities,
-    const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+__device__ __forceinline__ void fwd_one_view(
+    const int i, const int lane, int N, int K, int H, int W, int row_b, int row_e, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots, const float* __restrict__ cov6,
+    const float* __restrict__ opacities, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids, uint2* __restrict__ rects,
-    float4* __restrict__ sh_jac) {
-    // Output rows (48-byte records, 48-byte side-table rows) leave through LDS: a wave's 64 rows are 3 KB of
-    // consecutive memory, written as three 1 KB store instructions of whole lines.  One 16-byte store per lane and
-    // row word instead (48-byte lane stride) leaves every 128-byte line in three partial pieces, which cost this
-    // HBM-bound kernel 0.18 -> 0.30 ms once a second table was written that way.
-    __shared__ float4 out_stage[4][64 * 3];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    float4* st = out_stage[threadIdx.x >> 6];
+    float4* __restrict__ sh_jac, float4* st, float* sh_h, float& opacity_i, bool& requested) {
     const bool in_range = i < N;
     bool drawn = false;
     Geom g;
@@ -329,13 +323,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // screen-space mean says the Gaussian can be visible, BEFORE the covariance chain, so that they travel while it is
     // computed (issued after it, the kernel paid two memory latencies in a row: 0.222 -> 0.203 ms).
     constexpr int NBH = (DEG + 1) * (DEG + 1);
-    float sh_h[NBH * 3 + 3];
-    float opacity_i = 0.0f;
     if (in_range) {
         project_mean(i, H, W, view, proj, means3D, g);
-        if (mean_near_frame(g, H, W)) {
+        if (!requested && mean_near_frame(g, H, W)) {
             if (!colors_precomp) load_sh<NBH, VEC4>(shs, i, K, sh_h);
             opacity_i = opacities[i];      // only copied into the record at the very end: loaded there, it was one more wait
+            requested = true;
         }
         project_cov(i, H, W, row_b, row_e, proj, scales, rots, cov6, g);
         drawn = g.drawn;
@@ -413,6 +406,69 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         st[3 * lane + 2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(ry));
     }
     write_rows(splat);
+}
+
+template <int DEG, bool VEC4, bool JAC>
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+    int N, int K, int H, int W, int row_b, int row_e, const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ campos, const float* __restrict__ means3D,
+    const float* __restrict__ scales, const float* __restrict__ rots,
+    const float* __restrict__ cov6, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    float4* __restrict__ splat, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ ids, uint2* __restrict__ rects,
+    float4* __restrict__ sh_jac) {
+    // Output rows (48-byte records, 48-byte side-table rows) leave through LDS: a wave's 64 rows are 3 KB of
+    // consecutive memory, written as three 1 KB store instructions of whole lines.  One 16-byte store per lane and
+    // row word instead (48-byte lane stride) leaves every 128-byte line in three partial pieces, which cost this
+    // HBM-bound kernel 0.18 -> 0.30 ms once a second table was written that way.
+    __shared__ float4 out_stage[4][64 * 3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float sh_h[(DEG + 1) * (DEG + 1) * 3 + 3];
+    float opacity_i = 0.0f;
+    bool requested = false;
+    fwd_one_view<DEG, VEC4, JAC>(i, threadIdx.x & 63, N, K, H, W, row_b, row_e, view, proj, campos, means3D, scales, rots, cov6,
+                                 opacities, shs, colors_precomp, splat, radii, tiles_touched, depth_keys, ids, rects, sh_jac,
+                                 out_stage[threadIdx.x >> 6], sh_h, opacity_i, requested);
+}
+
+// k views of the same Gaussians in one launch (the forward of the multi-view training step): the
+// 192 bytes of SH coefficients per Gaussian -- half of what the single-view kernel reads -- the mean, scale, rotation and
+// opacity are read ONCE and kept in registers over the views; per view the lane writes what the single-view kernel writes.
+struct FwdView {
+    const float* view;
+    const float* proj;
+    const float* campos;
+    float4* splat;
+    int32_t* radii;
+    uint32_t* tiles_touched;
+    uint32_t* depth_keys;
+    uint32_t* ids;
+    uint2* rects;
+    float4* sh_jac;
+    int H, W, row_b, row_e;
+};
+struct FwdViews {
+    FwdView v[GS_MAX_FWD_VIEWS];
+};
+
+template <int DEG, bool JAC>
+__global__ __launch_bounds__(256) void preprocess_fwd_views_kernel(
+    int N, int K, int nv, const FwdViews views, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rots, const float* __restrict__ cov6, const float* __restrict__ opacities,
+    const float* __restrict__ shs) {
+    __shared__ float4 out_stage[4][64 * 3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float sh_h[(DEG + 1) * (DEG + 1) * 3 + 3];
+    float opacity_i = 0.0f;
+    bool requested = false;
+    for (int v = 0; v < nv; ++v) {
+        const FwdView& w = views.v[v];
+        fwd_one_view<DEG, true, JAC>(i, threadIdx.x & 63, N, K, w.H, w.W, w.row_b, w.row_e, w.view, w.proj, w.campos, means3D,
+                                     scales, rots, cov6, opacities, shs, nullptr, w.splat, w.radii, w.tiles_touched,
+                                     w.depth_keys, w.ids, w.rects, w.sh_jac, out_stage[threadIdx.x >> 6], sh_h, opacity_i,
+                                     requested);
+    }
 }
 
 // MODE 0: scalar SH access; 1: 16-byte SH loads/stores per lane (rows 16-byte aligned);
@@ -1029,6 +1085,69 @@ extern "C" int gs_preprocess_fwd(int N, int K, int sh_degree, int H, int W, cons
         case 2: return launch_fwd<2>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, (float4*)sh_jac, stream);
         default: return launch_fwd<3>(vec4, N, K, H, W, tile_row_begin, tile_row_end, viewmatrix, projmatrix, campos, means3D, scales, rotations, cov3D_precomp, opacities, shs, colors_precomp, sp, radii, tiles_touched, depth_keys, ids, (uint2*)rects, (float4*)sh_jac, stream);
     }
+}
+
+extern "C" int gs_preprocess_fwd_views(int n_views, const GsFwdView* views, int N, int K, int sh_degree,
+                                       const float* means3D, const float* scales, const float* rotations,
+                                       const float* cov3D_precomp, const float* opacities, const float* shs,
+                                       const float* colors_precomp, void* stream_) {
+    GS_REQUIRE(n_views >= 0 && (n_views == 0 || views), "n_views = %d with views = %p", n_views, (const void*)views);
+    if (N == 0 || n_views == 0) return GS_OK;
+    const bool vec4 = shs && ((K * 3) % 4 == 0) && (((uintptr_t)shs & 15) == 0);
+    bool fused = vec4 && n_views > 1;
+    for (int v = 1; v < n_views; ++v) fused = fused && (views[v].sh_jac != nullptr) == (views[0].sh_jac != nullptr);
+    if (!fused) {     // the same work view by view
+        for (int v = 0; v < n_views; ++v) {
+            const GsFwdView& w = views[v];
+            const int rc = gs_preprocess_fwd(N, K, sh_degree, w.H, w.W, w.viewmatrix, w.projmatrix, w.campos, means3D, scales,
+                                             rotations, cov3D_precomp, opacities, shs, colors_precomp, w.splat, w.radii,
+                                             w.tiles_touched, w.depth_keys, w.ids, w.rects, w.tile_row_begin,
+                                             w.tile_row_end, w.sh_jac, stream_);
+            if (rc) return rc;
+        }
+        return GS_OK;
+    }
+    GS_REQUIRE(opacities, "null argument");
+    GS_REQUIRE(!rotations || ((uintptr_t)rotations & 15) == 0, "rotations must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid(gs_div_up(N, 256)), block(256);
+    const bool jac = views[0].sh_jac != nullptr;
+    for (int v0 = 0; v0 < n_views; v0 += GS_MAX_FWD_VIEWS) {
+        const int nv = n_views - v0 < GS_MAX_FWD_VIEWS ? n_views - v0 : GS_MAX_FWD_VIEWS;
+        FwdViews a = {};
+        for (int v = 0; v < nv; ++v) {
+            const GsFwdView& w = views[v0 + v];
+            const int rc = check_common(N, K, sh_degree, w.H, w.W, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp);
+            if (rc) return rc;
+            GS_REQUIRE(w.viewmatrix && w.projmatrix && w.campos && w.splat && w.radii && w.tiles_touched,
+                       "view %d: null argument", v0 + v);
+            GS_REQUIRE(((uintptr_t)w.splat & 15) == 0 && ((uintptr_t)w.sh_jac & 15) == 0,
+                       "view %d: splat and sh_jac must be 16-byte aligned", v0 + v);
+            GS_REQUIRE((w.depth_keys == nullptr) == (w.ids == nullptr) && (w.ids == nullptr) == (w.rects == nullptr),
+                       "view %d: depth_keys, ids and rects go together", v0 + v);
+            GS_REQUIRE(((uintptr_t)w.rects & 7) == 0, "view %d: rects must be 8-byte aligned", v0 + v);
+            GS_REQUIRE(w.tile_row_begin >= 0 && w.tile_row_end >= w.tile_row_begin, "view %d: bad tile row band [%d,%d)",
+                       v0 + v, w.tile_row_begin, w.tile_row_end);
+            a.v[v] = FwdView{w.viewmatrix, w.projmatrix, w.campos, (float4*)w.splat, w.radii, w.tiles_touched, w.depth_keys,
+                             w.ids, (uint2*)w.rects, (float4*)w.sh_jac, w.H, w.W, w.tile_row_begin, w.tile_row_end};
+        }
+#define GS_LAUNCH_FWD_VIEWS(D_, J_)                                                                                      \
+    hipLaunchKernelGGL((preprocess_fwd_views_kernel<D_, J_>), grid, block, 0, stream, N, K, nv, a, means3D, scales, rotations, \
+                       cov3D_precomp, opacities, shs)
+        switch (sh_degree * 2 + (jac ? 1 : 0)) {
+            case 0: GS_LAUNCH_FWD_VIEWS(0, false); break;
+            case 1: GS_LAUNCH_FWD_VIEWS(0, true); break;
+            case 2: GS_LAUNCH_FWD_VIEWS(1, false); break;
+            case 3: GS_LAUNCH_FWD_VIEWS(1, true); break;
+            case 4: GS_LAUNCH_FWD_VIEWS(2, false); break;
+            case 5: GS_LAUNCH_FWD_VIEWS(2, true); break;
+            case 6: GS_LAUNCH_FWD_VIEWS(3, false); break;
+            default: GS_LAUNCH_FWD_VIEWS(3, true); break;
+        }
+#undef GS_LAUNCH_FWD_VIEWS
+        GS_CHECK_LAUNCH("preprocess_fwd_views");
+    }
+    return GS_OK;
 }
 
 extern "C" int gs_preprocess_bwd(int N, int K, int sh_degree, int H, int W, const float* viewmatrix,

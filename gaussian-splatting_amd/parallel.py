@@ -212,13 +212,13 @@ class _RasterizeSharded(torch.autograd.Function):
             jac = None
             if need_grad and R.USE_SH_JAC and shs is not None and n > 0:
                 jac = torch.empty((world, n, R.sh_jac_row_floats()), dtype=torch.float32, device=dev)
-            radii = []
-            for v in range(world):
-                _, r, _, _, _, _ = R.preprocess(views[v], means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                                colors_precomp, out=(splat_s[v], dkeys_s[v], ids_scratch, rects_s[v]),
-                                                sh_jac=None if jac is None else jac[v])
-                radii.append(r)
-            radii = torch.stack(radii) if world else torch.empty((0, n), **i32)
+            # (one launch for all views: gs_preprocess_fwd_views reads the shard's coefficients once; every view writes the
+            # same ids into the scratch row, which nothing reads)
+            pre = R.preprocess_views(views, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp,
+                                     outs=[(splat_s[v], dkeys_s[v], ids_scratch, rects_s[v]) for v in range(world)],
+                                     sh_jacs=None if jac is None else [jac[v] for v in range(world)])
+            radii = torch.stack([p[1] for p in pre]) if world else torch.empty((0, n), **i32)
+            del pre
             # 2. records, depth keys and boxes of ALL Gaussians for MY view, in global index order
             splat = torch.empty((max(total, 1), 12), dtype=torch.float32, device=dev)[:total]
             dkeys = torch.empty((2, max(total, 1)), **i32)
@@ -407,7 +407,8 @@ def bucket_ranges(n: int, num_buckets: int, align: int = 256):
 
 
 class _RasterizeViews(torch.autograd.Function):
-    """k camera views of the same (replicated) Gaussians as ONE autograd node: the forward renders every view; the
+    """k camera views of the same (replicated) Gaussians as ONE autograd node: the forward runs the per-Gaussian stage
+    of all k views as one launch (gs_preprocess_fwd_views) and bins and composites view by view; the
     backward runs every view's tile backward, then the chain rule of ALL k views as one launch per Gaussian range
     (gs_preprocess_bwd_views: the views' sums never leave registers / LDS, no per-view gradient tensors, every gradient
     row written once) and all-reduces each range's gradients as soon as its launch is queued (see ViewShardedStep).
@@ -419,14 +420,28 @@ class _RasterizeViews(torch.autograd.Function):
         from . import rasterizer as R
         dev = means3D.device
         per_view = []
+        N = means3D.shape[0]
         with torch.cuda.device(dev):
-            for settings in views:
+            # the per-Gaussian stage of ALL views in one launch (gs_preprocess_fwd_views: the SH coefficients, half of what
+            # that stage reads, are read once), then binning and compositing view by view
+            i32 = dict(dtype=torch.int32, device=dev)
+            outs, jacs = [], []
+            for _ in views:
+                outs.append((torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N],
+                             torch.empty((2, max(N, 1)), **i32), torch.empty((2, max(N, 1)), **i32),
+                             torch.empty((max(N, 1), 2), **i32)[:N]))
+                jacs.append(torch.empty((N, R.sh_jac_row_floats()), dtype=torch.float32, device=dev)
+                            if (need_grad and R.USE_SH_JAC and shs is not None and N > 0) else None)
+            pre = R.preprocess_views(views, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp,
+                                     outs=[(o[0], o[1][0][:N], o[2][0][:N], o[3]) for o in outs],
+                                     sh_jacs=jacs if jacs and jacs[0] is not None else None)
+            for settings, o, jac, (splat, radii, tiles_touched, _, _, rects) in zip(views, outs, jacs, pre):
                 band = R._band(settings, None)
-                state = R.preprocess_and_bin(settings, means3D, opacities, scales, rotations, cov3D_precomp, shs,
-                                             colors_precomp, None, want_jac=need_grad)
+                state = R.bin_splats(settings, splat, radii, tiles_touched, o[1], o[2], rects)._replace(sh_jac=jac)
                 image, depth, alpha, aux, rows = R.render_forward(settings, state.splat, state.ranges, state.point_list,
                                                                   need_grad, t_eps, band)
                 per_view.append((state, image, depth, alpha, aux, rows, band))
+            del outs, pre
         k = len(views)
         ctx.k, ctx.views, ctx.t_eps, ctx.owner = k, list(views), float(t_eps), owner
         ctx.bands = [pv[6] for pv in per_view]

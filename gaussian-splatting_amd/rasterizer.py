@@ -189,6 +189,50 @@ def preprocess(settings: GaussianRasterizationSettings, means3D, opacities, scal
     return splat, radii, tiles_touched, dkeys, ids, rects
 
 
+def preprocess_views(views, means3D, opacities, scales, rotations, cov3D_precomp, shs, colors_precomp, outs=None,
+                     sh_jacs=None):
+    """gs_preprocess_fwd_views on the current stream: `preprocess` for k views of the same Gaussians in one launch (the
+    per-Gaussian inputs, above all the SH coefficients, are read once).  views = k settings; outs = k tuples
+    (splat, dkeys, ids, rects) as in `preprocess` (allocated here if None); sh_jacs = k side tables or None.
+    Returns k tuples (splat, radii, tiles_touched, dkeys, ids, rects)."""
+    lib = _lib.load()
+    dev = means3D.device
+    N, k = means3D.shape[0], len(views)
+    K = shs.shape[1] if shs is not None else 0
+    if len({int(st.sh_degree) for st in views}) > 1:
+        raise ValueError("the views of one call must share sh_degree")
+    i32 = dict(dtype=torch.int32, device=dev)
+    descs = (_lib.GsFwdView * max(k, 1))()
+    keep, res = [], []
+    for j, st in enumerate(views):
+        out = outs[j] if outs is not None else (
+            torch.empty((max(N, 1), 12), dtype=torch.float32, device=dev)[:N], torch.empty((max(N, 1),), **i32)[:N],
+            torch.empty((max(N, 1),), **i32)[:N], torch.empty((max(N, 1), 2), **i32)[:N])
+        splat, dkeys, ids, rects = out
+        if (tuple(splat.shape), tuple(dkeys.shape), tuple(ids.shape), tuple(rects.shape)) != ((N, 12), (N,), (N,), (N, 2)) \
+                or not all(t.is_contiguous() for t in out):
+            raise ValueError("preprocess_views: output buffers must be contiguous (N,12), (N,), (N,), (N,2)")
+        radii = torch.empty((N,), **i32)
+        tiles_touched = torch.empty((N,), **i32)
+        cams = [_camera_tensor(getattr(st, name), n, name, dev) for name, n in
+                (("viewmatrix", 16), ("projmatrix", 16), ("campos", 3))]
+        keep.append(cams)
+        jac = sh_jacs[j] if (sh_jacs is not None and shs is not None) else None
+        d = descs[j]
+        d.viewmatrix, d.projmatrix, d.campos = (t.data_ptr() for t in cams)
+        d.splat, d.radii, d.tiles_touched = splat.data_ptr(), radii.data_ptr(), tiles_touched.data_ptr()
+        d.depth_keys, d.ids, d.rects = dkeys.data_ptr(), ids.data_ptr(), rects.data_ptr()
+        d.sh_jac = _jac_ptr(jac, N).value if jac is not None else None
+        d.H, d.W = st.image_height, st.image_width
+        d.tile_row_begin, d.tile_row_end = _band(st, None)
+        res.append((splat, radii, tiles_touched, dkeys, ids, rects))
+    with _stage("preprocess_fwd"):
+        _lib.check(lib.gs_preprocess_fwd_views(k, descs, N, K, views[0].sh_degree if k else 0, _ptr(means3D), _ptr(scales),
+                                               _ptr(rotations), _ptr(cov3D_precomp), _ptr(opacities), _ptr(shs),
+                                               _ptr(colors_precomp), _stream()), "gs_preprocess_fwd_views")
+    return res
+
+
 # the forward leaves d colour / d dir for the backward (one backward launch that never re-reads the coefficients);
 # False = the two-launch backward that does (kept for callers of the C-ABI that pass no table)
 USE_SH_JAC = True

@@ -42,8 +42,8 @@ extern "C" {
  * gradient rows, sh_jac rows) or a precondition changes: a binding compares gs_version() with the GS_ABI_VERSION it was
  * written against before its first call (gaussian-splatting_amd/_lib.py does) -- a mismatch means shifted arguments.
  * 100: round 1.  200: round 2 (sh_jac arguments, 64-byte gradient rows with six doubles, gs_identify_tile_ranges writes the
- * whole table and wants 16-byte aligned keys).  300: round 3.  301: this header (gs_preprocess_bwd_views added). */
-#define GS_ABI_VERSION 301
+ * whole table and wants 16-byte aligned keys).  300: round 3.  302: this header (gs_preprocess_fwd_views and gs_preprocess_bwd_views added). */
+#define GS_ABI_VERSION 302
 int gs_version(void);            /* == GS_ABI_VERSION of the header the library was built from */
 const char* gs_last_error(void); /* message of this thread's last failing call */
 const char* gs_source_sha(void); /* hash of the sources this library was compiled from (csrc/source_sha.py), "unknown" outside the Makefile */
@@ -184,6 +184,34 @@ int gs_render_bwd(int H, int W, const void* splat, const uint32_t* ranges, const
                   const float* aux_rgb, const float* out_depth, const float* out_alpha,
                   const float* g_image, const float* g_depth, const float* g_alpha, float* grad_rows,
                   float t_eps, int tile_row_begin, int tile_row_end, void* stream);
+
+/*
+ * gs_preprocess_fwd for k views of the SAME Gaussians: equal to k calls of gs_preprocess_fwd, one per descriptor, with the
+ * per-Gaussian inputs -- above all the 12 K bytes of SH coefficients -- read once for all views.  No counterpart in the
+ * reference (one view per iteration, train.py:129-135); it is the forward of the multi-view training step of SURVEY.md 8e
+ * (config 4: 8 views per step, parallel.ViewShardedStep).
+ * views: HOST array of n_views descriptors (device pointers inside; read during the call, not kept): per view the camera
+ * and every output of gs_preprocess_fwd, with that function's meaning, alignment and NULL rules.
+ * One launch per GS_MAX_FWD_VIEWS views when shs is given with 16-byte aligned rows and either every view or no view has
+ * an sh_jac; any other combination of inputs runs view by view inside the call (same results).
+ */
+#define GS_MAX_FWD_VIEWS 8
+typedef struct GsFwdView {
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    void* splat;
+    int32_t* radii;
+    uint32_t* tiles_touched;
+    uint32_t* depth_keys;
+    uint32_t* ids;
+    void* rects;
+    float* sh_jac;
+    int32_t H, W, tile_row_begin, tile_row_end;
+} GsFwdView;
+int gs_preprocess_fwd_views(int n_views, const GsFwdView* views, int N, int K, int sh_degree, const float* means3D,
+                            const float* scales, const float* rotations, const float* cov3D_precomp,
+                            const float* opacities, const float* shs, const float* colors_precomp, void* stream);
 
 /*
  * Backward of gs_preprocess_fwd: chain rule from grad_rows to the rasterizer's inputs (autograd of

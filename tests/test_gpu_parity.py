@@ -701,6 +701,51 @@ def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant,k", [("sh_deg3_jac", 3), ("sh_deg3_no_jac", 2), ("sh_deg1_jac", 11), ("sh_deg0_K1", 3),
+                                       ("colors_cov3d", 2), ("sh_deg2_K9", 3), ("sh_deg3_jac", 1)])
+def test_preprocess_fwd_views_equals_view_by_view(dgr, variant, k):
+    """gs_preprocess_fwd_views (k views of the same Gaussians in one launch, the coefficients read once) against k calls of
+    gs_preprocess_fwd: every output of every view bit for bit -- records, radii, tiles touched, depth keys, ids, boxes,
+    side table.  k = 11 takes two launches (GS_MAX_FWD_VIEWS = 8); K = 1 and K = 9 rows are not 16-byte multiples and
+    colors_precomp has no coefficients: those run view by view inside the call."""
+    R = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    dev = torch.device("cuda:0")
+    N, H, W = 5003, 120, 168
+    K, deg = {"sh_deg3_jac": (16, 3), "sh_deg3_no_jac": (16, 3), "sh_deg1_jac": (4, 1), "sh_deg0_K1": (1, 0),
+              "colors_cov3d": (1, 0), "sh_deg2_K9": (9, 2)}[variant]
+    use_jac = variant.endswith("_jac") and not variant.endswith("_no_jac")
+    sc = syn.make_scene(N, K, H, W, seed=13, sh_degree=deg)
+    m3, sh, op, s, q = (getattr(sc, n).to(dev) for n in ("means3D", "shs", "opacities", "scales", "rotations"))
+    colors = cov6 = None
+    if variant == "colors_cov3d":
+        g = torch.Generator().manual_seed(1)
+        colors = torch.rand(N, 3, generator=g).to(dev)
+        Rm = torch.randn(N, 3, 3, generator=g) * 0.05
+        S = Rm @ Rm.transpose(1, 2) + 1e-4 * torch.eye(3)
+        cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous().to(dev)
+        sh = s = q = None
+    settings = [_scene_settings(dgr, syn.jitter_view(sc, 3 * j), dev) for j in range(k)]
+    want, want_jac = [], []
+    for st in settings:
+        jac = torch.full((N, R.sh_jac_row_floats()), float("nan"), device=dev) if use_jac else None
+        want.append(R.preprocess(st, m3, op, s, q, cov6, sh, colors, sh_jac=jac))
+        want_jac.append(jac)
+    jacs = [torch.full((N, R.sh_jac_row_floats()), float("nan"), device=dev) for _ in range(k)] if use_jac else None
+    got = R.preprocess_views(settings, m3, op, s, q, cov6, sh, colors, sh_jacs=jacs)
+    torch.cuda.synchronize()
+    names = ("splat", "radii", "tiles_touched", "depth_keys", "ids", "rects")
+    if k > 1:
+        drawn = torch.stack([w[1] > 0 for w in want])
+        assert int((drawn.any(0) & ~drawn.all(0)).sum()) > 0        # some Gaussians are drawn in some views only
+    for v in range(k):
+        for name, a, b in zip(names, got[v], want[v]):
+            assert torch.equal(a, b), (v, name)
+        if use_jac:
+            assert torch.equal(jacs[v], want_jac[v]), (v, "sh_jac")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant,k", [("sh_deg3_jac", 3), ("sh_deg1_jac", 2), ("sh_deg3_jac", 11), ("sh_deg3_no_jac", 3),
                                        ("colors_cov3d", 3), ("sh_deg3_K20_vec4", 2), ("sh_deg3_jac", 1)])
 def test_preprocess_bwd_views_equals_view_by_view_accumulation(dgr, variant, k):

@@ -582,6 +582,55 @@ def test_config4_eight_view_step_at_6M_vs_oracle_sum(dgr, oracle):
     assert m2d.grad.shape == (V, N, 3) and float(m2d.grad[5].abs().max()) > 0 and not torch.equal(m2d.grad[5], m2d.grad[6])
 
 
+@pytest.mark.parametrize("t_eps", [0.0, 1e-5])
+def test_multi_view_step_with_views_of_different_sizes_equals_view_by_view(dgr, t_eps):
+    """parallel.ViewShardedStep on one GPU with three views of TWO image sizes (the fused per-Gaussian launches take H, W
+    and the tile grid per view) against the plain rasterizer called view by view with autograd summing the gradients:
+    images, depths, alphas and radii bit-identical, per-view means2D gradients bit-identical, summed gradients within
+    2e-6 * max (the fused backward adds the views up in registers, autograd in memory: the same order)."""
+    syn = importlib.import_module("gaussian-splatting_amd.synthetic")
+    par = importlib.import_module("gaussian-splatting_amd.parallel")
+    dev = torch.device("cuda:0")
+    N, K = 20011, 16
+    sizes = [(120, 168), (203, 317), (120, 168)]
+    base = syn.make_scene(N, K, 203, 317, seed=21)
+    sets = []
+    for j, (H, W) in enumerate(sizes):
+        sc = syn.jitter_view(syn.Scene(**{**base.__dict__, "H": H, "W": W}), 7 * j)
+        sets.append(_scene_settings(dgr, sc, dev))
+    gen = torch.Generator().manual_seed(5)
+    Gs = [torch.rand(3, H, W, generator=gen).to(dev) * 2 - 1 for (H, W) in sizes]
+    Gz = [torch.rand(1, H, W, generator=gen).to(dev) - 0.5 for (H, W) in sizes]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def leaves():
+        return {k: v.clone().requires_grad_(True) for k, v in _scene_inputs(base, dev).items()}
+
+    a = leaves()
+    want = []
+    for st, G, Z in zip(sets, Gs, Gz):
+        m2d = torch.zeros((N, 3), device=dev, requires_grad=True)
+        img, radii, depth, alpha = dgr.GaussianRasterizer(st, t_eps=t_eps)(
+            means3D=a["means3D"], means2D=m2d, shs=a["shs"], opacities=a["opacities"], scales=a["scales"],
+            rotations=a["rotations"])
+        ((img * G).sum() + (depth * Z).sum() + alpha.sum()).backward()
+        want.append((img.detach(), radii, depth.detach(), alpha.detach(), m2d.grad))
+    b = leaves()
+    m2d = torch.zeros((3, N, 3), device=dev, requires_grad=True)
+    images, radii, depths, alphas = par.ViewShardedStep(sets, t_eps=t_eps)(
+        means3D=b["means3D"], means2D=m2d, shs=b["shs"], opacities=b["opacities"], scales=b["scales"],
+        rotations=b["rotations"])
+    sum((img * G).sum() + (d * Z).sum() + al.sum() for img, d, al, G, Z in zip(images, depths, alphas, Gs, Gz)).backward()
+    torch.cuda.synchronize()
+    for j in range(3):
+        assert torch.equal(images[j].detach(), want[j][0]) and torch.equal(radii[j], want[j][1]), j
+        assert torch.equal(depths[j].detach(), want[j][2]) and torch.equal(alphas[j].detach(), want[j][3]), j
+        assert torch.equal(m2d.grad[j], want[j][4]), j
+    for k in names:
+        lim = 2e-6 * float(a[k].grad.abs().max())
+        assert float((a[k].grad - b[k].grad).abs().max()) <= lim, k
+
+
 def test_config5_4k_forward_vs_oracle_and_bands(dgr, oracle):
     """10 M Gaussians at 3840x2160, forward only, both modes; the 8 tile-row bands of the sharded render equal the frame
     (compared in the exact mode: the last image _full_size_case returns is the default mode's, so it is re-rendered)."""

@@ -56,7 +56,7 @@ PROTOTYPES = {
     "gs_preprocess_fwd_views": (_i, [_i, C.POINTER(GsFwdView), _i, _i, _i] + [_vp] * 7 + [_vp]),
     "gs_preprocess_bwd_views": (_i, [_i, C.POINTER(GsBwdView), _i, _i, _i] + [_vp] * 14 + [_i, _vp]),
     "gs_scan_workspace_bytes": (_sz, [_ll]),
-    "gs_scan_tiles": (_i, [_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "gs_scan_tiles": (_i, [_ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "gs_duplicate_with_keys": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "gs_sort_workspace_bytes": (_sz, [_ll]),
     "gs_sort_pairs": (_i, [_ll, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
@@ -77,7 +77,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 302     # GS_ABI_VERSION of the include/gsplat.h these prototypes were written against
+ABI_VERSION = 303     # GS_ABI_VERSION of the include/gsplat.h these prototypes were written against
 
 
 def load():

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
 // 24 MB table at 3 M Gaussians) and leaves it in rect_out[r] for the final pass and for
 // duplicate_with_keys, which then read everything coalesced.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_rect_kernel(
-    const uint2* __restrict__ rects, const uint32_t* __restrict__ order,
+    const uint2* __restrict__ rects, const uint32_t* __restrict__ order, const uint32_t* __restrict__ sorted_keys,
     uint2* __restrict__ rect_out, long long n, int row_b, int row_e, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
     const long long base = (long long)blockIdx.x * SCAN_TILE;
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_rect_kernel(
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         const long long idx = base + (long long)j * SCAN_THREADS + threadIdx.x;  // coalesced
         if (idx < n) {
-            const uint2 r = rects[order[idx]];
+            // a rank whose depth key is 0xFFFFFFFF holds a Gaussian that is not drawn (they sort last): its box is all
+            // zero, so it is not fetched -- one coalesced 4-byte read instead of a random line
+            const bool culled = sorted_keys && sorted_keys[idx] == 0xFFFFFFFFu;
+            const uint2 r = culled ? make_uint2(0u, 0u) : rects[order[idx]];
             rect_out[idx] = r;
             GsTileSpan t;
             s += gs_tile_span(r.x, r.y, row_b, row_e, t);
@@ -148,7 +151,7 @@ extern "C" size_t gs_scan_workspace_bytes(long long n) {
     return (size_t)(nblocks + 1) * sizeof(uint32_t);
 }
 
-extern "C" int gs_scan_tiles(long long N, const void* rects, const uint32_t* order, void* rect_in_order,
+extern "C" int gs_scan_tiles(long long N, const void* rects, const uint32_t* order, const uint32_t* sorted_depth_keys, void* rect_in_order,
                              uint32_t* offsets, uint32_t* total_dev, void* workspace, uint32_t* host_total,
                              int tile_row_begin, int tile_row_end, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -163,7 +166,7 @@ extern "C" int gs_scan_tiles(long long N, const void* rects, const uint32_t* ord
         const int nblocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
         uint32_t* sums = (uint32_t*)workspace;
         hipLaunchKernelGGL(scan_reduce_rect_kernel, dim3(nblocks), dim3(SCAN_THREADS), 0, stream, (const uint2*)rects,
-                           order, (uint2*)rect_in_order, N, tile_row_begin, tile_row_end, sums);
+                           order, sorted_depth_keys, (uint2*)rect_in_order, N, tile_row_begin, tile_row_end, sums);
         GS_CHECK_LAUNCH("scan_reduce_rect");
         if (nblocks <= SCAN_FUSE_MAX) {
             hipLaunchKernelGGL((scan_final_rect_kernel<true>), dim3(nblocks), dim3(SCAN_THREADS), 0, stream,

@@ -278,6 +278,7 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
         _lib.check(lib.gs_sort_pairs(N, None, 0, 32, _ptr(dkeys[0]), _ptr(ids[0]), _ptr(dkeys[1]), _ptr(ids[1]),
                                        _ptr(sort_ws), ws_bytes, C.byref(in_b), st), "gs_sort_pairs")
     order = ids[1 if in_b.value else 0][:N]
+    sorted_dkeys = dkeys[1 if in_b.value else 0][:N] if SKIP_CULLED_RANKS else None     # 0xFFFFFFFF = not drawn: its box is not fetched
     if before_scan is not None:
         before_scan()
     offsets = torch.empty((N,), **i32)
@@ -322,7 +323,7 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
     out = None
     if cap > 0:
         with _stage("scan_tiles"):
-            _lib.check(lib.gs_scan_tiles(N, _ptr(rects), _ptr(order), _ptr(rect_in_order),
+            _lib.check(lib.gs_scan_tiles(N, _ptr(rects), _ptr(order), _ptr(sorted_dkeys), _ptr(rect_in_order),
                                          _ptr(offsets), _ptr(total), _ptr(scan_ws), None, row_b, row_e, st),
                        "gs_scan_tiles")
         pinned, event = _readback_slot(dev)
@@ -336,7 +337,7 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
     else:
         host_total = C.c_uint32(0)
         with _stage("scan_tiles"):
-            _lib.check(lib.gs_scan_tiles(N, _ptr(rects), _ptr(order), _ptr(rect_in_order),
+            _lib.check(lib.gs_scan_tiles(N, _ptr(rects), _ptr(order), _ptr(sorted_dkeys), _ptr(rect_in_order),
                                          _ptr(offsets), _ptr(total), _ptr(scan_ws), C.byref(host_total), row_b,
                                          row_e, st), "gs_scan_tiles")
         D = int(host_total.value)
@@ -346,6 +347,9 @@ def bin_splats(settings, splat, radii, tiles_touched, dkeys, ids, rects, tile_ro
     keys, point_list, ranges = out
     return BinningState(splat, radii, tiles_touched, order, offsets, D, keys[:D], point_list[:D], ranges)
 
+
+# gs_scan_tiles gets the sorted depth keys and skips the box gather of ranks that are not drawn (False: gathers every rank)
+SKIP_CULLED_RANKS = True
 
 # per-device state of the optimistic binning: pair capacity learnt from earlier frames, and a pinned
 # 4-byte slot + event for the asynchronous read-back of D

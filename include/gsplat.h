@@ -42,8 +42,8 @@ extern "C" {
  * gradient rows, sh_jac rows) or a precondition changes: a binding compares gs_version() with the GS_ABI_VERSION it was
  * written against before its first call (gaussian-splatting_amd/_lib.py does) -- a mismatch means shifted arguments.
  * 100: round 1.  200: round 2 (sh_jac arguments, 64-byte gradient rows with six doubles, gs_identify_tile_ranges writes the
- * whole table and wants 16-byte aligned keys).  300: round 3.  302: this header (gs_preprocess_fwd_views and gs_preprocess_bwd_views added). */
-#define GS_ABI_VERSION 302
+ * whole table and wants 16-byte aligned keys).  300: round 3.  303: this header (gs_preprocess_fwd_views and gs_preprocess_bwd_views added, gs_scan_tiles takes the sorted depth keys). */
+#define GS_ABI_VERSION 303
 int gs_version(void);            /* == GS_ABI_VERSION of the header the library was built from */
 const char* gs_last_error(void); /* message of this thread's last failing call */
 const char* gs_source_sha(void); /* hash of the sources this library was compiled from (csrc/source_sha.py), "unknown" outside the Makefile */
@@ -94,10 +94,13 @@ size_t gs_scan_workspace_bytes(long long N);
 /* For every depth rank r: rect_in_order[r] (N x 2 uint32) = rects[order[r]], the box of the Gaussian
  * of that rank, and offsets[r] = exclusive scan of the number of tiles of those boxes inside the band
  * of tile rows.  *total_dev = D; host_total (host pointer, may be NULL) receives D after a stream
- * synchronise.  This gather is the only random access of the binning stage. */
-int gs_scan_tiles(long long N, const void* rects, const uint32_t* order, void* rect_in_order, uint32_t* offsets,
-                  uint32_t* total_dev, void* workspace, uint32_t* host_total, int tile_row_begin,
-                  int tile_row_end, void* stream);
+ * synchronise.  This gather is the only random access of the binning stage.
+ * sorted_depth_keys (may be NULL): the depth keys in rank order, as the depth sort left them.  A rank whose key is
+ * 0xFFFFFFFF holds a Gaussian that is not drawn (gs_preprocess_fwd gives those that key and an all-zero box): with the
+ * keys given, such a rank's box is not fetched (rect_in_order[r] = 0, 0) -- same result, fewer random reads. */
+int gs_scan_tiles(long long N, const void* rects, const uint32_t* order, const uint32_t* sorted_depth_keys,
+                  void* rect_in_order, uint32_t* offsets, uint32_t* total_dev, void* workspace, uint32_t* host_total,
+                  int tile_row_begin, int tile_row_end, void* stream);
 /* keys[o] = tile id (row-major), vals[o] = Gaussian index order[r], for o in [offsets[r], offsets[r] +
  * tiles of rect_in_order[r]), tiles of one Gaussian in row-major order.  Pairs with o >= capacity (the
  * number of pairs keys/vals can hold) are dropped, so a caller may size the buffers from an estimate,

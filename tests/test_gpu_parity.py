@@ -434,13 +434,32 @@ def test_scan_tiles_offsets_and_total(n, band):
     total = torch.full((1,), -1, dtype=torch.int32, device=dev)
     ws = torch.empty(max(16, L.gs_scan_workspace_bytes(n)), dtype=torch.uint8, device=dev)
     p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
-    rc = L.gs_scan_tiles(n, p(d_rects), p(d_order), p(d_rio), p(d_off), p(total), p(ws), None, rb, re,
+    rc = L.gs_scan_tiles(n, p(d_rects), p(d_order), None, p(d_rio), p(d_off), p(total), p(ws), None, rb, re,
                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, L.gs_last_error()
     torch.cuda.synchronize()
     assert int(total.item()) == int(cnt.sum())
     assert np.array_equal(d_rio.cpu().numpy().view(np.uint32), r)
     assert np.array_equal(d_off.cpu().numpy().view(np.uint32), want)
+    # with the sorted depth keys: ranks whose key is 0xFFFFFFFF (Gaussians that are not drawn: all-zero boxes, sorted last)
+    # are not fetched.  The last third of the ranks is culled here; garbage in THEIR table rows proves they are not read.
+    ncull = n // 3
+    keys = np.sort(rng.integers(0, 0xFFFFFFFE, n, dtype=np.uint64)).astype(np.uint32)
+    keys[n - ncull:] = 0xFFFFFFFF
+    rects2 = rects.copy()
+    rects2[order[n - ncull:]] = 0xDEADBEEF
+    r2, cnt2 = r.copy(), cnt.copy()
+    r2[n - ncull:], cnt2[n - ncull:] = 0, 0
+    want2 = np.concatenate([[0], np.cumsum(cnt2)[:-1]]).astype(np.uint32)
+    d_rects2, d_keys = t(rects2), t(keys)
+    d_rio.fill_(-1), d_off.fill_(-1), total.fill_(-1)
+    rc = L.gs_scan_tiles(n, p(d_rects2), p(d_order), p(d_keys), p(d_rio), p(d_off), p(total), p(ws), None, rb, re,
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.gs_last_error()
+    torch.cuda.synchronize()
+    assert int(total.item()) == int(cnt2.sum())
+    assert np.array_equal(d_rio.cpu().numpy().view(np.uint32), r2)
+    assert np.array_equal(d_off.cpu().numpy().view(np.uint32), want2)
 
 
 def test_backward_twice_and_unused_outputs(dgr):

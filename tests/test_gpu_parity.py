@@ -770,7 +770,7 @@ def test_preprocess_bwd_accumulate_adds_views(dgr, variant):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,k", [("sh_deg3_jac", 3), ("sh_deg3_no_jac", 2), ("sh_deg1_jac", 11), ("sh_deg0_K1", 3),
-                                       ("colors_cov3d", 2), ("sh_deg2_K9", 3), ("sh_deg3_jac", 1)])
+                                       ("colors_cov3d", 2), ("sh_deg2_K9", 3), ("sh_deg3_jac", 1), ("sh_deg3_cov3d_jac", 3)])
 def test_preprocess_fwd_views_equals_view_by_view(dgr, variant, k):
     """gs_preprocess_fwd_views (k views of the same Gaussians in one launch, the coefficients read once) against k calls of
     gs_preprocess_fwd: every output of every view bit for bit -- records, radii, tiles touched, depth keys, ids, boxes,
@@ -781,18 +781,20 @@ def test_preprocess_fwd_views_equals_view_by_view(dgr, variant, k):
     dev = torch.device("cuda:0")
     N, H, W = 5003, 120, 168
     K, deg = {"sh_deg3_jac": (16, 3), "sh_deg3_no_jac": (16, 3), "sh_deg1_jac": (4, 1), "sh_deg0_K1": (1, 0),
-              "colors_cov3d": (1, 0), "sh_deg2_K9": (9, 2)}[variant]
+              "colors_cov3d": (1, 0), "sh_deg2_K9": (9, 2), "sh_deg3_cov3d_jac": (16, 3)}[variant]
     use_jac = variant.endswith("_jac") and not variant.endswith("_no_jac")
     sc = syn.make_scene(N, K, H, W, seed=13, sh_degree=deg)
     m3, sh, op, s, q = (getattr(sc, n).to(dev) for n in ("means3D", "shs", "opacities", "scales", "rotations"))
     colors = cov6 = None
-    if variant == "colors_cov3d":
+    if "cov3d" in variant:
         g = torch.Generator().manual_seed(1)
-        colors = torch.rand(N, 3, generator=g).to(dev)
         Rm = torch.randn(N, 3, 3, generator=g) * 0.05
         S = Rm @ Rm.transpose(1, 2) + 1e-4 * torch.eye(3)
         cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous().to(dev)
-        sh = s = q = None
+        s = q = None
+        if variant == "colors_cov3d":
+            colors = torch.rand(N, 3, generator=g).to(dev)
+            sh = None
     settings = [_scene_settings(dgr, syn.jitter_view(sc, 3 * j), dev) for j in range(k)]
     want, want_jac = [], []
     for st in settings:
@@ -815,7 +817,7 @@ def test_preprocess_fwd_views_equals_view_by_view(dgr, variant, k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,k", [("sh_deg3_jac", 3), ("sh_deg1_jac", 2), ("sh_deg3_jac", 11), ("sh_deg3_no_jac", 3),
-                                       ("colors_cov3d", 3), ("sh_deg3_K20_vec4", 2), ("sh_deg3_jac", 1)])
+                                       ("colors_cov3d", 3), ("sh_deg3_K20_vec4", 2), ("sh_deg3_jac", 1), ("sh_deg3_cov3d_jac", 3)])
 def test_preprocess_bwd_views_equals_view_by_view_accumulation(dgr, variant, k):
     """gs_preprocess_bwd_views (k views of the same Gaussians in one launch, the backward of the multi-view step) against
     gs_preprocess_bwd called view by view with `accumulate`: the same sums in the same order, so the results agree to
@@ -828,19 +830,21 @@ def test_preprocess_bwd_views_equals_view_by_view_accumulation(dgr, variant, k):
     dev = torch.device("cuda:0")
     N, H, W = 5000, 120, 168
     K, deg = {"sh_deg3_jac": (16, 3), "sh_deg1_jac": (4, 1), "sh_deg3_no_jac": (16, 3), "colors_cov3d": (1, 0),
-              "sh_deg3_K20_vec4": (20, 3)}[variant]
+              "sh_deg3_K20_vec4": (20, 3), "sh_deg3_cov3d_jac": (16, 3)}[variant]
     use_jac = variant.endswith("_jac") and not variant.endswith("_no_jac")
     fused = use_jac and k > 1
     sc = syn.make_scene(N, K, H, W, seed=12, sh_degree=deg)
     m3, sh, op, s, q = (getattr(sc, n).to(dev) for n in ("means3D", "shs", "opacities", "scales", "rotations"))
     colors = cov6 = None
-    if variant == "colors_cov3d":
+    if "cov3d" in variant:
         g = torch.Generator().manual_seed(1)
-        colors = torch.rand(N, 3, generator=g).to(dev)
         Rm = torch.randn(N, 3, 3, generator=g) * 0.05
         S = Rm @ Rm.transpose(1, 2) + 1e-4 * torch.eye(3)
         cov6 = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous().to(dev)
-        sh = s = q = None
+        s = q = None
+        if variant == "colors_cov3d":
+            colors = torch.rand(N, 3, generator=g).to(dev)
+            sh = None
     settings = [_scene_settings(dgr, syn.jitter_view(sc, 3 * j), dev) for j in range(k)]
     gr = torch.Generator().manual_seed(3)
     rows = [torch.cat([torch.randn(N, 6, generator=gr, dtype=torch.float64).view(torch.float32),

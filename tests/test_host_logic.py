@@ -149,3 +149,31 @@ def test_view_sharded_step_argument_checks(dgr):
         step(means3D=m, shs=sh, opacities=op, scales=sc, rotations=q)
     assert par.shard_views(8, 1, 4) == [1, 5] and par.shard_views(8, 0, 1) == list(range(8))
     assert isinstance(par.ViewShardedRasterizer(_settings(dgr)), par.ViewShardedStep)
+    with pytest.raises(ValueError, match="sh_degree"):     # one model, one active degree: the fused per-Gaussian launches take one
+        par.ViewShardedStep([_settings(dgr), _settings(dgr, sh_degree=2)])
+
+
+def test_multi_view_entry_points_host_checks(dgr):
+    """rasterizer.preprocess_views / preprocess_backward_views (gs_preprocess_fwd_views / gs_preprocess_bwd_views): the
+    argument checks that need no GPU, and the descriptor structs against the header's field order."""
+    R = importlib.import_module("gaussian-splatting_amd.rasterizer")
+    L = importlib.import_module("gaussian-splatting_amd._lib")
+    m, sh, op = torch.zeros(4, 3), torch.zeros(4, 16, 3), torch.zeros(4, 1)
+    sc, q = torch.ones(4, 3), torch.zeros(4, 4)
+    two = [_settings(dgr), _settings(dgr, sh_degree=1)]
+    with pytest.raises(ValueError, match="sh_degree"):
+        R.preprocess_views(two, m, op, sc, q, None, sh, None)
+    with pytest.raises(ValueError, match="sh_degree"):
+        R.preprocess_backward_views(two, m, op, sc, q, None, sh, None, [None, None], [None, None], [True] * 8)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "gsplat.h")).read()
+    for cls, name in ((L.GsFwdView, "GsFwdView"), (L.GsBwdView, "GsBwdView")):
+        body = header[header.index("typedef struct " + name):header.index("} " + name + ";")]
+        fields = []
+        for line in body.splitlines()[1:]:
+            line = line.strip().rstrip(";")
+            if line:
+                fields += [f.strip(" *") for f in line.split(" ", 1)[1].replace("float*", "").replace("void*", "").split(",")]
+        fields = [f.split("*")[-1].strip() for f in fields]
+        assert [f[0] for f in cls._fields_] == fields, (name, fields)
+    assert L.MAX_BWD_VIEWS == 8 and "#define GS_MAX_BWD_VIEWS 8" in header and "#define GS_MAX_FWD_VIEWS 8" in header

@@ -33,3 +33,6 @@ for frac in (0.15, 0.5, 1.0):
     k = np.zeros(n, dtype=np.uint32); k[n - int(frac * n):] = 0xFFFFFFFF
     run(perm, t(k), f"random order, last {int(frac * 100)} % of the ranks not fetched")
 run(ident, None, "identity order (coalesced gather)")
+# the same number of random fetches out of a smaller footprint (what a table of 4-byte boxes would be: half the bytes)
+for div in (2, 4, 8):
+    run(t(rng.integers(0, n // div, n).astype(np.uint32)), None, f"random ranks into the first 1/{div} of the table ({8 * n // div >> 20} MB)")

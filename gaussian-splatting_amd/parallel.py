@@ -584,8 +584,10 @@ class ViewShardedStep:
     no gradient tensors, no read-modify-write pass and no collective); the C-ABI takes base pointers and a count, so a
     range is a row slice of every per-Gaussian tensor -- and launches that range's all-reduce (one grouped RCCL call over
     its slices of the gradient tensors) right after its kernel is queued: RCCL's stream starts on range b while this
-    stream computes range b + 1, and only the last range's transfer is exposed.  One exchange per step, whatever the number of local views: the wire time is amortised
-    over 8 / world views.  The gradients autograd hands to the parameters are already summed over views and ranks
+    stream computes range b + 1, and only the last range's transfer is exposed.  One exchange per step, whatever the number
+    of local views: the wire time is amortised over 8 / world views.  The forward runs the per-Gaussian stage of all local
+    views as one launch too (gs_preprocess_fwd_views: the SH coefficients are read once per step, not once per view).
+    The gradients autograd hands to the parameters are already summed over views and ranks
     (divided by the world size if `average`).  means2D (optional, (k, N, 3)): its gradient is the per-view screen-space
     gradient (the densification statistic); it and radii (k of them) are not exchanged -- fold them into the per-Gaussian
     statistics view by view, then call reduce_densify_stats ONCE per step.
